@@ -1,0 +1,66 @@
+// kernels.h — host-side launchers of the HIP kernels (internal; the public ABI is include/esahrnet.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace esa {
+
+// ---- implicit-GEMM convolution on MFMA (conv_mfma.hip) -------------------------------------
+struct ConvParams {
+    const char* x;      // SB input  [N][H][W][Cinp]
+    char* y;            // SB output [N][OH][OW][Coutp]
+    const char* res;    // SB residual (same shape as y) or nullptr
+    const uint4* w;     // packed split-bf16 weights, fragment order (see pack_conv_weights)
+    const float* bias;  // f32 [Coutp]
+    int N, H, W, OH, OW;
+    int Cinp, Coutp;    // multiples of 32
+    int relu;
+};
+// k in {1,3}, stride in {1,2}, pad = (k-1)/2.  Returns hipError_t as int.
+int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream);
+// bytes of the packed weight image for a conv with padded channel counts
+size_t packed_weight_bytes(int coutp, int cinp, int k);
+// host-side packing: w f32 [cout][cin][k][k] -> dst (packed_weight_bytes), zero padded
+void pack_conv_weights(const float* w, int cout, int cin, int k, int coutp, int cinp, void* dst);
+
+// ---- stem conv1: f32 NCHW -> SB, 3x3 s1, cin in {1..4}, cout = multiple of 32 (stem.hip) ---
+struct StemParams {
+    const float* x;     // f32 [N][cin][H][W]
+    char* y;            // SB [N][H][W][cout]
+    const float* w;     // f32 [cout/8][cin][9][8]  (repacked: 8 consecutive couts innermost)
+    const float* bias;  // f32 [cout]
+    int N, H, W, cin, cout;
+};
+int launch_stem(const StemParams& p, hipStream_t stream);
+
+// ---- cross-resolution fuse: y = relu?(sum_i up(x_i)) on SB tensors (fuse.hip) ---------------
+struct FuseParams {
+    const char* x[4];
+    int h[4], w[4];     // source resolution of each term (== H,W for same-resolution terms)
+    int nterms;
+    char* y;
+    int N, H, W, Cp;
+    int relu;
+};
+int launch_fuse(const FuseParams& p, hipStream_t stream);
+
+// ---- head tail: up x2 (align_corners=True) + concat raw input + 3x3 conv -> f32 NCHW (head.hip)
+struct FinalParams {
+    const char* h3;     // SB [N][H/2][W/2][Cp]  (last_layer.3 output, K valid channels)
+    const float* x0;    // f32 [N][cin][H][W]
+    float* out;         // f32 [N][K][H][W]
+    const float* w;     // f32 [K+cin][9][K]   (repacked: output channel innermost)
+    const float* bias;  // f32 [K]
+    int N, H, W, h, wd; // h,wd = resolution of h3
+    int K, cin, Cp;
+};
+int launch_final(const FinalParams& p, hipStream_t stream);
+
+// ---- arg-max + log-quadratic refine (keypoints.hip) ----------------------------------------
+int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, hipStream_t stream);
+
+// ---- layout conversion f32 NCHW <-> SB (layout.hip) ----------------------------------------
+int launch_nchw_to_sb(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s);
+int launch_sb_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s);
+
+}  // namespace esa

@@ -1,0 +1,66 @@
+// layout.hip — f32 NCHW <-> SB (split-bf16 NHWC) conversion.  Used by the per-operator test
+// entry points and by esahrnet_tap_read; the network itself enters SB through the stem kernel
+// and leaves it through the head kernel.
+#include "kernels.h"
+#include "sb.h"
+
+namespace esa {
+namespace {
+
+__global__ __launch_bounds__(256) void nchw_to_sb_kernel(const float* x, int N, int C, int H, int W,
+                                                         char* y, int Cp, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int G = Cp >> 3;
+    const int c8 = (int)(idx % G);
+    const long long pix = idx / G;
+    const long long hw = (long long)H * W;
+    const int n = (int)(pix / hw);
+    const long long s = pix - (long long)n * hw;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c8 * 8 + i;
+        v[i] = c < C ? x[((size_t)n * C + c) * hw + s] : 0.f;
+    }
+    uint4 hi, lo;
+    split8(v, hi, lo);
+    char* o = y + (size_t)pix * (size_t)(Cp * 4) + c8 * 32;
+    *reinterpret_cast<uint4*>(o) = hi;
+    *reinterpret_cast<uint4*>(o + 16) = lo;
+}
+
+__global__ __launch_bounds__(256) void sb_to_nchw_kernel(const char* x, int N, int C, int H, int W,
+                                                         int Cp, float* y, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over (n, c, s), s fastest
+    if (idx >= total) return;
+    const long long hw = (long long)H * W;
+    const long long s = idx % hw;
+    const long long nc = idx / hw;
+    const int c = (int)(nc % C);
+    const int n = (int)(nc / C);
+    const char* a = x + ((size_t)n * hw + s) * (size_t)(Cp * 4) + (c >> 3) * 32 + (c & 7) * 2;
+    const uint32_t hi = *reinterpret_cast<const unsigned short*>(a);
+    const uint32_t lo = *reinterpret_cast<const unsigned short*>(a + 16);
+    y[idx] = bf16_bits_to_f32(hi) + bf16_bits_to_f32(lo);
+}
+
+}  // namespace
+
+int launch_nchw_to_sb(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s) {
+    const long long total = (long long)N * H * W * (Cp >> 3);
+    const long long nblk = (total + 255) / 256;
+    if (nblk <= 0 || nblk > 0x7fffffffLL || (Cp & 7) || C > Cp) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(nchw_to_sb_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, N, C, H, W, y, Cp, total);
+    return (int)hipGetLastError();
+}
+
+int launch_sb_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s) {
+    const long long total = (long long)N * C * H * W;
+    const long long nblk = (total + 255) / 256;
+    if (nblk <= 0 || nblk > 0x7fffffffLL || C > Cp) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sb_to_nchw_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, N, C, H, W, Cp, y, total);
+    return (int)hipGetLastError();
+}
+
+}  // namespace esa

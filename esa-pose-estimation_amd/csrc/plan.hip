@@ -1,0 +1,702 @@
+// plan.hip — host runtime behind the C-ABI (include/esahrnet.h): stage table -> static plan
+// (list of fused kernels over SB tensors), weight packing, workspace planning, forward.
+//
+// Reference being replaced: models/seg_hrnet.py:260-423 (module construction) and :425-473
+// (forward).  The plan is NOT a transcription of the module tree:
+//   * every BatchNorm2d is folded into its convolution by the host before esahrnet_set_conv;
+//   * conv + bias + residual + ReLU are one kernel (conv_mfma.hip);
+//   * the cross-resolution sums are one kernel per output branch (fuse.hip);
+//   * last_layer[0] (1x1, 480->480 on the concatenated, up-sampled branches, 26 % of the
+//     reference's MACs) is evaluated per branch at the branch's own resolution and summed by the
+//     fuse kernel — a 1x1 convolution commutes with bilinear interpolation (both linear, the
+//     interpolation weights act per channel), so conv(cat(up(x_b))) = sum_b up(conv_b(x_b))
+//     exactly in real arithmetic; it needs 8x fewer MACs and never builds the 480-channel concat;
+//   * last_layer[6] + concat + output_layer are one kernel (head.hip).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/esahrnet.h"
+#include "kernels.h"
+
+namespace esa {
+int final_kt(int K);
+}
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIP_OK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+inline int pad32(int c) { return (c + 31) & ~31; }
+
+struct ConvSpec {               // one Conv2d of the reference module tree
+    std::string name, bn;
+    int cin, cout, k, stride, level;   // level: output resolution level (0 = crop, 1 = /2, ...)
+    bool has_bias, relu;
+    std::vector<float> w, b;    // folded weights as handed over by the host
+    bool set = false;
+};
+
+struct DevConv {                // one MFMA convolution launch (a ConvSpec or a cin-slice of one)
+    int spec;                   // index into specs
+    int c0, c1;                 // input-channel slice of the spec
+    bool use_bias;
+    int cinp, coutp;
+    void* w = nullptr;          // device, packed
+    float* bias = nullptr;      // device, f32 [coutp]
+};
+
+enum OpKind { OP_STEM, OP_CONV, OP_FUSE, OP_FINAL };
+
+struct Tensor {
+    int C, Cp, level;
+    std::string tap;            // name for esahrnet_tap_read, "" if anonymous
+    int def = -1, last = -1;    // op indices
+    size_t off = 0;             // per-shape plan
+};
+
+struct Op {
+    OpKind kind;
+    int dconv = -1;             // OP_CONV
+    int in = -1, out = -1, res = -1;
+    int terms[4] = {-1, -1, -1, -1};
+    int nterms = 0;
+    bool relu = false;
+};
+
+struct ShapePlan {
+    int n = 0, h = 0, w = 0;
+    bool keep = false;
+    size_t bytes = 0;
+    std::vector<int> lh, lw;    // resolution per level
+};
+
+}  // namespace
+
+struct esahrnet_ctx {
+    esahrnet_cfg cfg;
+    int device;
+    std::vector<ConvSpec> specs;
+    std::map<std::string, int> spec_by_name;
+    std::vector<DevConv> dconvs;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    int spec_stem = -1, spec_final = -1;
+    float *stem_w = nullptr, *stem_b = nullptr, *final_w = nullptr, *final_b = nullptr;
+    bool committed = false;
+    bool keep = false;
+    ShapePlan sp;
+    int max_level = 0;
+};
+
+namespace {
+
+struct Builder {
+    esahrnet_ctx& c;
+    explicit Builder(esahrnet_ctx& ctx) : c(ctx) {}
+
+    int spec(const std::string& name, const std::string& bn, int cin, int cout, int k, int stride,
+             int level, bool bias, bool relu) {
+        ConvSpec s;
+        s.name = name; s.bn = bn; s.cin = cin; s.cout = cout; s.k = k; s.stride = stride;
+        s.level = level; s.has_bias = bias; s.relu = relu;
+        c.specs.push_back(s);
+        c.spec_by_name[name] = (int)c.specs.size() - 1;
+        c.max_level = std::max(c.max_level, level);
+        return (int)c.specs.size() - 1;
+    }
+    int tensor(int C, int level, const std::string& tap = "") {
+        Tensor t;
+        t.C = C; t.Cp = pad32(C); t.level = level; t.tap = tap;
+        c.tensors.push_back(t);
+        return (int)c.tensors.size() - 1;
+    }
+    void use(int t, int op) {
+        if (t < 0) return;
+        c.tensors[t].last = std::max(c.tensors[t].last, op);
+    }
+    // conv op on a spec (optionally a cin slice); returns the output tensor
+    int conv(int sp, int in, int res, bool relu, const std::string& tap = "", int c0 = 0, int c1 = -1,
+             bool use_bias = true) {
+        const ConvSpec& s = c.specs[sp];
+        DevConv d;
+        d.spec = sp; d.c0 = c0; d.c1 = c1 < 0 ? s.cin : c1; d.use_bias = use_bias;
+        d.cinp = pad32(d.c1 - d.c0); d.coutp = pad32(s.cout);
+        c.dconvs.push_back(d);
+        Op o;
+        o.kind = OP_CONV; o.dconv = (int)c.dconvs.size() - 1; o.in = in; o.res = res; o.relu = relu;
+        o.out = tensor(s.cout, s.level, tap);
+        const int idx = (int)c.ops.size();
+        c.tensors[o.out].def = idx;
+        use(in, idx); use(res, idx);
+        c.ops.push_back(o);
+        return o.out;
+    }
+    int fuse(const std::vector<int>& terms, int C, int level, bool relu, const std::string& tap = "") {
+        Op o;
+        o.kind = OP_FUSE; o.nterms = (int)terms.size(); o.relu = relu;
+        o.out = tensor(C, level, tap);
+        const int idx = (int)c.ops.size();
+        c.tensors[o.out].def = idx;
+        for (int i = 0; i < o.nterms; ++i) { o.terms[i] = terms[i]; use(terms[i], idx); }
+        c.ops.push_back(o);
+        return o.out;
+    }
+    // BasicBlock (seg_hrnet.py:32-61): conv-bn-relu-conv-bn (+res) relu
+    int basic_block(const std::string& p, int x, int cin, int cout, int level, const std::string& tap) {
+        int res = x;
+        const int c1 = spec(p + ".conv1", p + ".bn1", cin, cout, 3, 1, level, false, true);
+        const int c2 = spec(p + ".conv2", p + ".bn2", cout, cout, 3, 1, level, false, true);
+        if (cin != cout) {
+            const int d = spec(p + ".downsample.0", p + ".downsample.1", cin, cout, 1, 1, level, false, false);
+            res = conv(d, x, -1, false);
+        }
+        const int o = conv(c1, x, -1, true);
+        return conv(c2, o, res, true, tap);
+    }
+};
+
+int build_plan(esahrnet_ctx& c) {
+    const esahrnet_cfg& g = c.cfg;
+    Builder B(c);
+    const int sw = g.stem_width;
+    // ---- stem (seg_hrnet.py:265-270, 426-431) ----
+    c.spec_stem = B.spec("conv1", "bn1", g.cin, sw, 3, 1, 0, false, true);
+    {
+        Op o; o.kind = OP_STEM; o.out = B.tensor(sw, 0, "stem1");
+        c.tensors[o.out].def = 0;
+        c.ops.push_back(o);
+    }
+    int x = B.conv(B.spec("conv2", "bn2", sw, sw, 3, 2, 1, false, true), c.ops[0].out, -1, true, "stem2");
+    // ---- layer1 (:277, :432) ----
+    int cin = sw;
+    const int nb1 = g.blocks[0][0];
+    for (int k = 0; k < nb1; ++k) {
+        x = B.basic_block("layer1." + std::to_string(k), x, cin, g.widths[0], 1, k == nb1 - 1 ? "layer1" : "");
+        cin = g.widths[0];
+    }
+    std::vector<int> ys{x};
+    std::vector<int> pre{g.widths[0]};
+    for (int s = 2; s <= 4; ++s) {
+        int nb = 0;
+        while (nb < ESAHRNET_MAX_BRANCHES && g.blocks[s - 1][nb] > 0) ++nb;
+        if (nb < (int)pre.size() || nb > (int)pre.size() + 1)
+            return fail("stage %d: %d branches after %zu (must grow by at most one)", s, nb, pre.size());
+        std::vector<int> cur(g.widths, g.widths + nb);
+        const std::string t = "transition" + std::to_string(s - 1);
+        // ---- transition (:343-377, wiring :434-457: new branch from ys.back()) ----
+        std::vector<int> xs;
+        for (int i = 0; i < nb; ++i) {
+            if (i < (int)pre.size()) {
+                if (pre[i] != cur[i]) {
+                    const std::string q = t + "." + std::to_string(i);
+                    xs.push_back(B.conv(B.spec(q + ".0", q + ".1", pre[i], cur[i], 3, 1, 1 + i, false, true), ys[i], -1, true));
+                } else {
+                    xs.push_back(ys[i]);
+                }
+            } else {
+                int tt = ys.back();
+                const int nconv = i + 1 - (int)pre.size();
+                for (int j = 0; j < nconv; ++j) {
+                    const std::string q = t + "." + std::to_string(i) + "." + std::to_string(j);
+                    const int co = j == nconv - 1 ? cur[i] : pre.back();
+                    tt = B.conv(B.spec(q + ".0", q + ".1", pre.back(), co, 3, 2, (int)pre.size() + j + 1, false, true), tt, -1, true);
+                }
+                xs.push_back(tt);
+            }
+        }
+        // ---- HighResolutionModule x NUM_MODULES (:105-249) ----
+        for (int m = 0; m < g.modules[s - 1]; ++m) {
+            const std::string p = "stage" + std::to_string(s) + "." + std::to_string(m);
+            for (int b = 0; b < nb; ++b)
+                for (int k = 0; k < g.blocks[s - 1][b]; ++k)
+                    xs[b] = B.basic_block(p + ".branches." + std::to_string(b) + "." + std::to_string(k),
+                                          xs[b], cur[b], cur[b], 1 + b, "");
+            std::vector<int> outs;
+            for (int i = 0; i < nb; ++i) {
+                std::vector<int> terms;
+                for (int j = 0; j < nb; ++j) {
+                    const std::string q = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j);
+                    if (j == i) {
+                        terms.push_back(xs[j]);
+                    } else if (j > i) {          // 1x1 + BN on the low-res grid; up-sampled inside fuse
+                        terms.push_back(B.conv(B.spec(q + ".0", q + ".1", cur[j], cur[i], 1, 1, 1 + j, false, false), xs[j], -1, false));
+                    } else {                     // chain of 3x3 s2 (:198-217)
+                        int tt = xs[j];
+                        for (int k = 0; k < i - j; ++k) {
+                            const bool last = k == i - j - 1;
+                            const std::string qq = q + "." + std::to_string(k);
+                            tt = B.conv(B.spec(qq + ".0", qq + ".1", cur[j], last ? cur[i] : cur[j], 3, 2, 1 + j + k + 1, false, !last), tt, -1, !last);
+                        }
+                        terms.push_back(tt);
+                    }
+                }
+                const bool final_module = m == g.modules[s - 1] - 1;
+                outs.push_back(B.fuse(terms, cur[i], 1 + i, true,
+                                      final_module ? "stage" + std::to_string(s) + "." + std::to_string(i) : ""));
+            }
+            xs = outs;
+        }
+        ys = xs;
+        pre = cur;
+    }
+    // ---- head (:313-340, :461-469) ----
+    int tot = 0;
+    for (int v : pre) tot += v;
+    const int K = g.num_keypoints;
+    const int l0 = B.spec("last_layer.0", "last_layer.1", tot, tot, 1, 1, 1, true, true);
+    const int l3 = B.spec("last_layer.3", "last_layer.4", tot, K, 1, 1, 1, true, true);
+    c.spec_final = B.spec("output_layer.0", "", K + g.cin, K, 3, 1, 0, true, false);
+    std::vector<int> hterms;
+    int off = 0;
+    for (size_t b = 0; b < ys.size(); ++b) {
+        // the slice runs at branch b's own resolution: fix the output level of the slice conv
+        const int save = c.specs[l0].level;
+        c.specs[l0].level = 1 + (int)b;
+        hterms.push_back(B.conv(l0, ys[b], -1, false, "", off, off + pre[b], b == 0));
+        c.specs[l0].level = save;
+        off += pre[b];
+    }
+    const int h0 = B.fuse(hterms, tot, 1, true, "head0");
+    const int h3 = B.conv(l3, h0, -1, true, "head3");
+    {
+        Op o; o.kind = OP_FINAL; o.in = h3;
+        B.use(h3, (int)c.ops.size());
+        c.ops.push_back(o);
+    }
+    return 0;
+}
+
+void level_dims(const esahrnet_ctx& c, int h, int w, std::vector<int>& lh, std::vector<int>& lw) {
+    lh.assign(c.max_level + 1, 0);
+    lw.assign(c.max_level + 1, 0);
+    lh[0] = h; lw[0] = w;
+    for (int l = 1; l <= c.max_level; ++l) { lh[l] = (lh[l - 1] + 1) / 2; lw[l] = (lw[l - 1] + 1) / 2; }
+}
+
+int check_shape(const esahrnet_ctx& c, int n, int h, int w) {
+    if (n <= 0) return fail("batch must be positive (got %d)", n);
+    if (h < 16 || w < 16 || (h & 1) || (w & 1))
+        return fail("crop %dx%d: height and width must be even and >= 16 "
+                    "(UpsamplingBilinear2d(x2) output must match the crop, seg_hrnet.py:330,469)", h, w);
+    (void)c;
+    return 0;
+}
+
+// first-fit interval allocator over op order; tensors die after their last use
+int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
+    if (c.sp.n == n && c.sp.h == h && c.sp.w == w && c.sp.keep == c.keep) return 0;
+    if (check_shape(c, n, h, w)) return 1;
+    ShapePlan sp;
+    sp.n = n; sp.h = h; sp.w = w; sp.keep = c.keep;
+    level_dims(c, h, w, sp.lh, sp.lw);
+    struct Free { size_t off, len; };
+    std::vector<Free> free_list;
+    size_t top = 0;
+    auto bytes_of = [&](const Tensor& t) {
+        size_t b = (size_t)n * sp.lh[t.level] * sp.lw[t.level] * t.Cp * 4;
+        return (b + 255) & ~(size_t)255;
+    };
+    auto alloc = [&](size_t len) {
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].len >= len) {
+                const size_t off = free_list[i].off;
+                free_list[i].off += len; free_list[i].len -= len;
+                if (!free_list[i].len) free_list.erase(free_list.begin() + i);
+                return off;
+            }
+        const size_t off = top;
+        top += len;
+        return off;
+    };
+    auto release = [&](size_t off, size_t len) {
+        free_list.push_back({off, len});
+        std::sort(free_list.begin(), free_list.end(), [](const Free& a, const Free& b) { return a.off < b.off; });
+        for (size_t i = 0; i + 1 < free_list.size();)
+            if (free_list[i].off + free_list[i].len == free_list[i + 1].off) {
+                free_list[i].len += free_list[i + 1].len;
+                free_list.erase(free_list.begin() + i + 1);
+            } else ++i;
+        if (!free_list.empty() && free_list.back().off + free_list.back().len == top) {
+            top = free_list.back().off;
+            free_list.pop_back();
+        }
+    };
+    size_t high = 0;
+    for (size_t oi = 0; oi < c.ops.size(); ++oi) {
+        const Op& o = c.ops[oi];
+        if (o.out >= 0) {
+            c.tensors[o.out].off = alloc(bytes_of(c.tensors[o.out]));
+            high = std::max(high, std::max(top, c.tensors[o.out].off + bytes_of(c.tensors[o.out])));
+        }
+        if (!c.keep)
+            for (Tensor& t : c.tensors)
+                if (t.def >= 0 && t.def <= (int)oi && t.last == (int)oi) release(t.off, bytes_of(t));
+        high = std::max(high, top);
+    }
+    sp.bytes = high;
+    c.sp = sp;
+    return 0;
+}
+
+void free_weights(esahrnet_ctx& c) {
+    for (DevConv& d : c.dconvs) {
+        if (d.w) (void)hipFree(d.w);
+        if (d.bias) (void)hipFree(d.bias);
+        d.w = nullptr; d.bias = nullptr;
+    }
+    for (float** p : {&c.stem_w, &c.stem_b, &c.final_w, &c.final_b})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    c.committed = false;
+}
+
+template <typename T>
+int upload(const std::vector<T>& host, void** dev) {
+    HIP_OK(hipMalloc(dev, host.size() * sizeof(T)));
+    HIP_OK(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace
+
+// ============================================ C ABI ============================================
+extern "C" {
+
+const char* esahrnet_last_error(void) { return g_err; }
+int esahrnet_abi_version(void) { return ESAHRNET_ABI_VERSION; }
+
+int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
+    if (!cfg || !out) return fail("esahrnet_create: null argument");
+    if (cfg->final_conv_kernel != 1) return fail("FINAL_CONV_KERNEL=%d unsupported (reference default 1)", cfg->final_conv_kernel);
+    if (cfg->cin < 1 || cfg->cin > 4) return fail("cin=%d unsupported (1..4)", cfg->cin);
+    if (cfg->num_keypoints < 1 || esa::final_kt(cfg->num_keypoints) < 0) return fail("num_keypoints=%d unsupported (1..32)", cfg->num_keypoints);
+    if (cfg->stem_width < 1 || cfg->blocks[0][0] < 1) return fail("bad stem_width/blocks");
+    for (int s = 1; s < 4; ++s)
+        if (cfg->modules[s] < 1) return fail("NUM_MODULES of stage %d must be >= 1", s + 1);
+    for (int b = 0; b < ESAHRNET_MAX_BRANCHES; ++b)
+        if (cfg->blocks[3][b] > 0 && cfg->widths[b] < 1) return fail("width of branch %d must be positive", b);
+    esahrnet_ctx* c = new esahrnet_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    if (build_plan(*c)) { delete c; return 1; }
+    *out = c;
+    return 0;
+}
+
+int esahrnet_destroy(esahrnet_handle h) {
+    if (!h) return 0;
+    if (h->committed) { (void)hipSetDevice(h->device); }
+    free_weights(*h);
+    delete h;
+    return 0;
+}
+
+int esahrnet_conv_count(esahrnet_handle h) { return h ? (int)h->specs.size() : -1; }
+
+int esahrnet_conv_desc_get(esahrnet_handle h, int i, esahrnet_conv_desc* out) {
+    if (!h || !out || i < 0 || i >= (int)h->specs.size()) return fail("conv_desc_get: bad index %d", i);
+    const ConvSpec& s = h->specs[i];
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", s.name.c_str());
+    snprintf(out->bn, sizeof out->bn, "%s", s.bn.c_str());
+    out->cin = s.cin; out->cout = s.cout; out->k = s.k; out->stride = s.stride;
+    out->has_bias = s.has_bias; out->relu = s.relu;
+    return 0;
+}
+
+int esahrnet_set_conv(esahrnet_handle h, int i, const float* w, const float* b) {
+    if (!h || !w || !b || i < 0 || i >= (int)h->specs.size()) return fail("set_conv: bad argument (index %d)", i);
+    ConvSpec& s = h->specs[i];
+    const size_t nw = (size_t)s.cout * s.cin * s.k * s.k;
+    s.w.assign(w, w + nw);
+    s.b.assign(b, b + s.cout);
+    for (size_t j = 0; j < nw; ++j)
+        if (!std::isfinite(s.w[j])) return fail("set_conv(%s): non-finite weight", s.name.c_str());
+    s.set = true;
+    return 0;
+}
+
+int esahrnet_commit(esahrnet_handle h) {
+    if (!h) return fail("commit: null handle");
+    for (const ConvSpec& s : h->specs)
+        if (!s.set) return fail("commit: weights of '%s' were never set", s.name.c_str());
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("commit: no HIP device visible — the MI355X kernels cannot run (no CPU fallback exists)");
+    HIP_OK(hipSetDevice(h->device));
+    free_weights(*h);
+    std::vector<char> packed;
+    for (DevConv& d : h->dconvs) {
+        const ConvSpec& s = h->specs[d.spec];
+        const int cin = d.c1 - d.c0, taps = s.k * s.k;
+        std::vector<float> w((size_t)s.cout * cin * taps);
+        for (int co = 0; co < s.cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < taps; ++t)
+                    w[((size_t)co * cin + ci) * taps + t] = s.w[((size_t)co * s.cin + d.c0 + ci) * taps + t];
+        packed.assign(esa::packed_weight_bytes(d.coutp, d.cinp, s.k), 0);
+        esa::pack_conv_weights(w.data(), s.cout, cin, s.k, d.coutp, d.cinp, packed.data());
+        if (upload(packed, &d.w)) return 1;
+        std::vector<float> bias(d.coutp, 0.f);
+        if (d.use_bias) std::copy(s.b.begin(), s.b.end(), bias.begin());
+        if (upload(bias, reinterpret_cast<void**>(&d.bias))) return 1;
+    }
+    {   // stem: [cout/8][cin][9][8]
+        const ConvSpec& s = h->specs[h->spec_stem];
+        const int coutp = pad32(s.cout);
+        std::vector<float> w((size_t)coutp * s.cin * 9, 0.f), b(coutp, 0.f);
+        for (int co = 0; co < s.cout; ++co) {
+            b[co] = s.b[co];
+            for (int ci = 0; ci < s.cin; ++ci)
+                for (int t = 0; t < 9; ++t)
+                    w[(((size_t)(co >> 3) * s.cin + ci) * 9 + t) * 8 + (co & 7)] = s.w[((size_t)co * s.cin + ci) * 9 + t];
+        }
+        if (upload(w, reinterpret_cast<void**>(&h->stem_w)) || upload(b, reinterpret_cast<void**>(&h->stem_b))) return 1;
+    }
+    {   // final: [K+cin][9][KT]
+        const ConvSpec& s = h->specs[h->spec_final];
+        const int kt = esa::final_kt(s.cout);
+        std::vector<float> w((size_t)s.cin * 9 * kt, 0.f), b(kt, 0.f);
+        for (int co = 0; co < s.cout; ++co) {
+            b[co] = s.b[co];
+            for (int ci = 0; ci < s.cin; ++ci)
+                for (int t = 0; t < 9; ++t)
+                    w[((size_t)ci * 9 + t) * kt + co] = s.w[((size_t)co * s.cin + ci) * 9 + t];
+        }
+        if (upload(w, reinterpret_cast<void**>(&h->final_w)) || upload(b, reinterpret_cast<void**>(&h->final_b))) return 1;
+    }
+    h->committed = true;
+    return 0;
+}
+
+int esahrnet_set_debug_keep(esahrnet_handle h, int keep) {
+    if (!h) return fail("null handle");
+    h->keep = keep != 0;
+    return 0;
+}
+
+int esahrnet_workspace_bytes(esahrnet_handle h, int n, int height, int width, size_t* bytes) {
+    if (!h || !bytes) return fail("workspace_bytes: null argument");
+    if (plan_shape(*h, n, height, width)) return 1;
+    *bytes = h->sp.bytes;
+    return 0;
+}
+
+int esahrnet_forward(esahrnet_handle h, const void* x_dev, int n, int height, int width,
+                     void* heat_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream_) {
+    if (!h || !x_dev || !heat_dev || !ws_dev) return fail("forward: null argument");
+    if (!h->committed) return fail("forward: esahrnet_commit has not been called");
+    if (plan_shape(*h, n, height, width)) return 1;
+    if (ws_bytes < h->sp.bytes) return fail("forward: workspace too small (%zu < %zu)", ws_bytes, h->sp.bytes);
+    if (reinterpret_cast<uintptr_t>(ws_dev) & 255) return fail("forward: workspace must be 256-byte aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char* ws = static_cast<char*>(ws_dev);
+    const ShapePlan& sp = h->sp;
+    auto T = [&](int t) { return ws + h->tensors[t].off; };
+    for (const Op& o : h->ops) {
+        int rc = 0;
+        switch (o.kind) {
+            case OP_STEM: {
+                const Tensor& t = h->tensors[o.out];
+                esa::StemParams p{static_cast<const float*>(x_dev), T(o.out), h->stem_w, h->stem_b,
+                                  n, height, width, h->cfg.cin, t.Cp};
+                rc = esa::launch_stem(p, stream);
+                break;
+            }
+            case OP_CONV: {
+                const DevConv& d = h->dconvs[o.dconv];
+                const ConvSpec& s = h->specs[d.spec];
+                const Tensor& ti = h->tensors[o.in];
+                const Tensor& to = h->tensors[o.out];
+                if (ti.Cp != d.cinp || to.Cp != d.coutp) return fail("plan bug: channel mismatch at %s", s.name.c_str());
+                esa::ConvParams p{};
+                p.x = T(o.in); p.y = T(o.out); p.res = o.res >= 0 ? T(o.res) : nullptr;
+                p.w = static_cast<const uint4*>(d.w); p.bias = d.bias;
+                p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level];
+                p.OH = sp.lh[to.level]; p.OW = sp.lw[to.level];
+                p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu;
+                rc = esa::launch_conv(p, s.k, s.stride, stream);
+                break;
+            }
+            case OP_FUSE: {
+                const Tensor& to = h->tensors[o.out];
+                esa::FuseParams p{};
+                p.nterms = o.nterms;
+                for (int i = 0; i < o.nterms; ++i) {
+                    const Tensor& ti = h->tensors[o.terms[i]];
+                    if (ti.Cp != to.Cp) return fail("plan bug: fuse channel mismatch");
+                    p.x[i] = T(o.terms[i]); p.h[i] = sp.lh[ti.level]; p.w[i] = sp.lw[ti.level];
+                }
+                p.y = T(o.out); p.N = n; p.H = sp.lh[to.level]; p.W = sp.lw[to.level]; p.Cp = to.Cp;
+                p.relu = o.relu;
+                rc = esa::launch_fuse(p, stream);
+                break;
+            }
+            case OP_FINAL: {
+                const Tensor& ti = h->tensors[o.in];
+                esa::FinalParams p{};
+                p.h3 = T(o.in); p.x0 = static_cast<const float*>(x_dev); p.out = static_cast<float*>(heat_dev);
+                p.w = h->final_w; p.bias = h->final_b;
+                p.N = n; p.H = height; p.W = width; p.h = sp.lh[ti.level]; p.wd = sp.lw[ti.level];
+                p.K = h->cfg.num_keypoints; p.cin = h->cfg.cin; p.Cp = ti.Cp;
+                rc = esa::launch_final(p, stream);
+                break;
+            }
+        }
+        if (rc) return fail("forward: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
+    return 0;
+}
+
+int esahrnet_keypoints(const void* heat_dev, int n, int k, int height, int width, void* kp_dev,
+                       esahrnet_stream stream) {
+    if (!heat_dev || !kp_dev || n <= 0 || k <= 0) return fail("keypoints: bad argument");
+    const int rc = esa::launch_keypoints(static_cast<const float*>(heat_dev), n * k, height, width,
+                                         static_cast<float*>(kp_dev), static_cast<hipStream_t>(stream));
+    if (rc) return fail("keypoints: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+int esahrnet_flops_per_crop(esahrnet_handle h, int height, int width, double* flops) {
+    if (!h || !flops) return fail("flops_per_crop: null argument");
+    std::vector<int> lh, lw;
+    level_dims(*h, height, width, lh, lw);
+    double f = 0;
+    for (const ConvSpec& s : h->specs)
+        f += 2.0 * lh[s.level] * lw[s.level] * s.cout * s.cin * s.k * s.k;
+    *flops = f;
+    return 0;
+}
+
+int esahrnet_launch_count(esahrnet_handle h) { return h ? (int)h->ops.size() : -1; }
+
+int esahrnet_tap_count(esahrnet_handle h) {
+    if (!h) return -1;
+    int n = 0;
+    for (const Tensor& t : h->tensors) n += !t.tap.empty();
+    return n;
+}
+
+int esahrnet_tap_name(esahrnet_handle h, int index, char* out, size_t cap) {
+    if (!h || !out) return fail("tap_name: null argument");
+    int n = 0;
+    for (const Tensor& t : h->tensors)
+        if (!t.tap.empty() && n++ == index) { snprintf(out, cap, "%s", t.tap.c_str()); return 0; }
+    return fail("tap_name: index %d out of range", index);
+}
+
+static const Tensor* find_tap(esahrnet_handle h, const char* name) {
+    for (const Tensor& t : h->tensors)
+        if (t.tap == name) return &t;
+    return nullptr;
+}
+
+int esahrnet_tap_shape(esahrnet_handle h, const char* name, int height, int width, int* c, int* th, int* tw) {
+    if (!h || !name || !c || !th || !tw) return fail("tap_shape: null argument");
+    const Tensor* t = find_tap(h, name);
+    if (!t) return fail("tap_shape: no tensor named '%s'", name);
+    std::vector<int> lh, lw;
+    level_dims(*h, height, width, lh, lw);
+    *c = t->C; *th = lh[t->level]; *tw = lw[t->level];
+    return 0;
+}
+
+int esahrnet_tap_read(esahrnet_handle h, const char* name, int n, int height, int width,
+                      const void* ws_dev, void* out_dev, esahrnet_stream stream) {
+    if (!h || !name || !ws_dev || !out_dev) return fail("tap_read: null argument");
+    if (!h->keep) return fail("tap_read: call esahrnet_set_debug_keep(h, 1) before the forward (buffers are recycled otherwise)");
+    const Tensor* t = find_tap(h, name);
+    if (!t) return fail("tap_read: no tensor named '%s'", name);
+    if (plan_shape(*h, n, height, width)) return 1;
+    const int rc = esa::launch_sb_to_nchw(static_cast<const char*>(ws_dev) + t->off, n, t->C,
+                                          h->sp.lh[t->level], h->sp.lw[t->level], t->Cp,
+                                          static_cast<float*>(out_dev), static_cast<hipStream_t>(stream));
+    if (rc) return fail("tap_read: %s", hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+// ---- stand-alone operators on f32 NCHW tensors (tests) ---------------------------------------
+int esahrnet_op_conv(const void* x_dev, int n, int cin, int height, int width, const float* w,
+                     const float* b, int cout, int k, int stride, int relu, const void* res_dev,
+                     void* y_dev, esahrnet_stream stream_) {
+    if (!x_dev || !w || !b || !y_dev) return fail("op_conv: null argument");
+    if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return fail("op_conv: k=%d stride=%d unsupported", k, stride);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int cinp = pad32(cin), coutp = pad32(cout);
+    const int oh = stride == 2 ? (height + 1) / 2 : height, ow = stride == 2 ? (width + 1) / 2 : width;
+    std::vector<char> packed(esa::packed_weight_bytes(coutp, cinp, k), 0);
+    esa::pack_conv_weights(w, cout, cin, k, coutp, cinp, packed.data());
+    std::vector<float> bias(coutp, 0.f);
+    std::copy(b, b + cout, bias.begin());
+    void *dw = nullptr, *db = nullptr, *xs = nullptr, *ys = nullptr, *rs = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() { for (void* p : {dw, db, xs, ys, rs}) if (p) (void)hipFree(p); };
+    if (upload(packed, &dw) || upload(bias, &db)) { cleanup(); return 1; }
+    const size_t xb = (size_t)n * height * width * cinp * 4, yb = (size_t)n * oh * ow * coutp * 4;
+    if (hipMalloc(&xs, xb) != hipSuccess || hipMalloc(&ys, yb) != hipSuccess ||
+        (res_dev && hipMalloc(&rs, yb) != hipSuccess)) { cleanup(); return fail("op_conv: hipMalloc failed"); }
+    rc = esa::launch_nchw_to_sb(static_cast<const float*>(x_dev), n, cin, height, width, static_cast<char*>(xs), cinp, stream);
+    if (!rc && res_dev) rc = esa::launch_nchw_to_sb(static_cast<const float*>(res_dev), n, cout, oh, ow, static_cast<char*>(rs), coutp, stream);
+    if (!rc) {
+        esa::ConvParams p{};
+        p.x = static_cast<const char*>(xs); p.y = static_cast<char*>(ys); p.res = static_cast<const char*>(rs);
+        p.w = static_cast<const uint4*>(dw); p.bias = static_cast<const float*>(db);
+        p.N = n; p.H = height; p.W = width; p.OH = oh; p.OW = ow; p.Cinp = cinp; p.Coutp = coutp; p.relu = relu;
+        rc = esa::launch_conv(p, k, stride, stream);
+    }
+    if (!rc) rc = esa::launch_sb_to_nchw(static_cast<const char*>(ys), n, cout, oh, ow, coutp, static_cast<float*>(y_dev), stream);
+    hipError_t se = hipStreamSynchronize(stream);
+    cleanup();
+    if (rc) return fail("op_conv: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (se != hipSuccess) return fail("op_conv: %s", hipGetErrorString(se));
+    return 0;
+}
+
+int esahrnet_op_fuse(const void* const* xs_dev, const int* hs, const int* ws, int nterms, int n, int c,
+                     int height, int width, int relu, void* y_dev, esahrnet_stream stream_) {
+    if (!xs_dev || !hs || !ws || !y_dev || nterms < 1 || nterms > 4) return fail("op_fuse: bad argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int cp = pad32(c);
+    void* bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    auto cleanup = [&]() { for (void* p : bufs) if (p) (void)hipFree(p); };
+    int rc = 0;
+    esa::FuseParams p{};
+    p.nterms = nterms; p.N = n; p.H = height; p.W = width; p.Cp = cp; p.relu = relu;
+    for (int i = 0; i < nterms && !rc; ++i) {
+        if (hipMalloc(&bufs[i], (size_t)n * hs[i] * ws[i] * cp * 4) != hipSuccess) { cleanup(); return fail("op_fuse: hipMalloc failed"); }
+        rc = esa::launch_nchw_to_sb(static_cast<const float*>(xs_dev[i]), n, c, hs[i], ws[i], static_cast<char*>(bufs[i]), cp, stream);
+        p.x[i] = static_cast<const char*>(bufs[i]); p.h[i] = hs[i]; p.w[i] = ws[i];
+    }
+    if (!rc && hipMalloc(&bufs[4], (size_t)n * height * width * cp * 4) != hipSuccess) { cleanup(); return fail("op_fuse: hipMalloc failed"); }
+    p.y = static_cast<char*>(bufs[4]);
+    if (!rc) rc = esa::launch_fuse(p, stream);
+    if (!rc) rc = esa::launch_sb_to_nchw(p.y, n, c, height, width, cp, static_cast<float*>(y_dev), stream);
+    hipError_t se = hipStreamSynchronize(stream);
+    cleanup();
+    if (rc) return fail("op_fuse: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (se != hipSuccess) return fail("op_fuse: %s", hipGetErrorString(se));
+    return 0;
+}
+
+}  // extern "C"

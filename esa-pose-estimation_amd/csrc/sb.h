@@ -1,0 +1,62 @@
+// sb.h — the internal activation format and small device helpers (gfx950 only).
+//
+// "SB" = split-bf16 NHWC.  A tensor [N][H][W][Cp] (Cp = channels padded to a multiple of
+// 32) stores every value v as hi = bf16(v), lo = bf16(v - hi), i.e. ~16 mantissa bits.
+// Per pixel the Cp channels are laid out in groups of 8:  [c8][part(hi=0,lo=1)][8 x bf16],
+// 32 bytes per group, Cp*4 bytes per pixel.  One 16-byte chunk is exactly one MFMA
+// 16x16x32 bf16 operand fragment of one lane (8 consecutive K elements of one pixel), so
+// the convolution kernels move chunks HBM -> LDS -> VGPR without ever repacking them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+// Round-to-nearest-even f32 -> bf16 bits (finite inputs; the network never produces NaN
+// from finite weights/inputs).
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
+    __bf16 h = (__bf16)x;
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+
+__device__ __forceinline__ void split_bf16(float v, uint32_t& hi, uint32_t& lo) {
+    __bf16 h = (__bf16)v;
+    float r = v - (float)h;
+    __bf16 l = (__bf16)r;
+    hi = (uint32_t)__builtin_bit_cast(unsigned short, h);
+    lo = (uint32_t)__builtin_bit_cast(unsigned short, l);
+}
+
+// 4 floats -> 8 bytes of hi bf16 + 8 bytes of lo bf16
+__device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_bf16(v[i], h[i], l[i]);
+    hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
+__device__ __forceinline__ void join4(uint2 hi, uint2 lo, float v[4]) {
+    v[0] = bf16_bits_to_f32(hi.x & 0xffffu) + bf16_bits_to_f32(lo.x & 0xffffu);
+    v[1] = bf16_bits_to_f32(hi.x >> 16) + bf16_bits_to_f32(lo.x >> 16);
+    v[2] = bf16_bits_to_f32(hi.y & 0xffffu) + bf16_bits_to_f32(lo.y & 0xffffu);
+    v[3] = bf16_bits_to_f32(hi.y >> 16) + bf16_bits_to_f32(lo.y >> 16);
+}
+
+// 8 floats <-> one 32-byte channel group (hi chunk, lo chunk)
+__device__ __forceinline__ void split8(const float v[8], uint4& hi, uint4& lo) {
+    uint2 h0, l0, h1, l1;
+    split4(v, h0, l0);
+    split4(v + 4, h1, l1);
+    hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+__device__ __forceinline__ void join8(uint4 hi, uint4 lo, float v[8]) {
+    join4(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y), v);
+    join4(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), v + 4);
+}

@@ -1,0 +1,76 @@
+// stem.hip — stem conv1: 3x3 s1 p1 (cin 1..4 -> cout) + folded BN + ReLU, f32 NCHW in, SB out.
+//
+// Replaces conv1+bn1+relu of models/seg_hrnet.py:265-267, 426-428.  K = 9*cin <= 36 is far
+// too short for the matrix cores and the op is bound by its 256 B/pixel output write, so it is
+// plain f32 VALU: one thread per (pixel, 8-channel group) with the group index fastest across
+// lanes, i.e. the 8 lanes of a pixel write its 256 contiguous bytes and read the same 9*cin
+// inputs (served once by the L1).
+#include "kernels.h"
+#include "sb.h"
+
+namespace esa {
+namespace {
+
+__global__ __launch_bounds__(256) void stem_kernel(StemParams p, long long total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wsm = reinterpret_cast<float*>(smem);
+    const int G = p.cout >> 3;
+    const int wcount = G * p.cin * 72;
+    for (int i = threadIdx.x; i < wcount; i += 256) wsm[i] = p.w[i];
+    __syncthreads();
+
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % G);
+    long long pix = idx / G;
+    const int x = (int)(pix % p.W);
+    pix /= p.W;
+    const int y = (int)(pix % p.H);
+    const int n = (int)(pix / p.H);
+
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = p.bias[c8 * 8 + i];
+    for (int ci = 0; ci < p.cin; ++ci) {
+        const float* xp = p.x + ((size_t)(n * p.cin + ci) * p.H) * p.W;
+        const float* wp = wsm + (c8 * p.cin + ci) * 72;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = x + kx - 1;
+                float v = 0.f;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = xp[(size_t)yy * p.W + xx];
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp + (ky * 3 + kx) * 8);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wp + (ky * 3 + kx) * 8 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i] = fmaf(v, w0[i], acc[i]);
+                    acc[4 + i] = fmaf(v, w1[i], acc[4 + i]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fmaxf(acc[i], 0.f);
+    uint4 hi, lo;
+    split8(acc, hi, lo);
+    char* o = p.y + (((size_t)(n * p.H + y) * p.W + x) * p.cout) * 4 + c8 * 32;
+    *reinterpret_cast<uint4*>(o) = hi;
+    *reinterpret_cast<uint4*>(o + 16) = lo;
+}
+
+}  // namespace
+
+int launch_stem(const StemParams& p, hipStream_t stream) {
+    if ((p.cout & 31) || p.cin < 1 || p.cin > 4) return (int)hipErrorInvalidValue;
+    const long long total = (long long)p.N * p.H * p.W * (p.cout >> 3);
+    const long long nblk = (total + 255) / 256;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)(p.cout >> 3) * p.cin * 72 * sizeof(float);
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)nblk), dim3(256), lds, stream, p, total);
+    return (int)hipGetLastError();
+}
+
+}  // namespace esa

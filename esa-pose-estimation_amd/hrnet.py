@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's model interface for the MI355X path.
+
+Reference interface being mirrored:
+  * models/seg_hrnet.py:495-499     get_seg_model(cfg, **kwargs) -> nn.Module
+  * models/seg_hrnet.py:258-340     HighResolutionNet(config): parameters/buffers under the
+                                    reference's state_dict keys (strict load_state_dict of a
+                                    reference checkpoint works, val.py:64-66)
+  * models/seg_hrnet.py:425-473     net(x: f32 [N,Cin,H,W]) -> f32 [N,K,H,W], same device
+  * models/seg_hrnet.py:475-493     init_weights(pretrained)
+
+The module owns ordinary torch parameters (so .cuda(), .parameters(), .state_dict(),
+DataParallel's unwrap idiom `net.module.net` all behave), but forward() never runs a torch
+operator: it folds BN into the convolutions once per weight version, hands them to
+libesahrnet.so and enqueues the hand-written HIP kernels on torch's current stream.
+There is no CPU or eager fallback: without the library or without a GPU, forward raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .fold import fold_conv
+
+logger = logging.getLogger(__name__)
+BN_MOMENTUM = 0.01           # models/seg_hrnet.py:23 (irrelevant at inference, kept for parity)
+
+
+def _cfg_struct(config, cin: int, num_keypoints: int) -> _lib.Cfg:
+    extra = config.MODEL.EXTRA.HIGH_RESOLUTION_NET if hasattr(config, "MODEL") else \
+        config["MODEL"]["EXTRA"]["HIGH_RESOLUTION_NET"]
+    s = _lib.Cfg()
+    s.cin, s.num_keypoints, s.stem_width = cin, num_keypoints, 64
+    fk = extra["FINAL_CONV_KERNEL"] if "FINAL_CONV_KERNEL" in extra else 1
+    s.final_conv_kernel = int(fk)
+    for i in range(4):
+        st = extra[f"STAGE{i + 1}"]
+        if st["BLOCK"] != "BASIC":
+            raise ValueError(f"STAGE{i + 1}.BLOCK={st['BLOCK']!r}: only BASIC blocks are built "
+                             "(config/default.py:49-73 uses BASIC everywhere)")
+        if st["FUSE_METHOD"] != "SUM":
+            raise ValueError("only FUSE_METHOD='SUM' exists in the reference")
+        nb = int(st["NUM_BRANCHES"])
+        # same consistency checks as HighResolutionModule._check_branches (seg_hrnet.py:123-141)
+        if nb != len(st["NUM_BLOCKS"]):
+            raise ValueError("NUM_BRANCHES({}) <> NUM_BLOCKS({})".format(nb, len(st["NUM_BLOCKS"])))
+        if nb != len(st["NUM_CHANNELS"]):
+            raise ValueError("NUM_BRANCHES({}) <> NUM_CHANNELS({})".format(nb, len(st["NUM_CHANNELS"])))
+        if nb != i + 1:
+            raise ValueError(f"STAGE{i + 1} must have {i + 1} branches (got {nb})")
+        s.modules[i] = int(st["NUM_MODULES"])
+        for b in range(nb):
+            s.blocks[i][b] = int(st["NUM_BLOCKS"][b])
+            if i == 3:
+                s.widths[b] = int(st["NUM_CHANNELS"][b])
+            elif int(st["NUM_CHANNELS"][b]) != int(extra["STAGE4"]["NUM_CHANNELS"][b]):
+                raise ValueError("branch widths must agree across stages")
+    return s
+
+
+class _Node(nn.Module):
+    """Pure container used to reproduce the reference's dotted state_dict names."""
+
+
+def _place(root: nn.Module, dotted: str, leaf: nn.Module):
+    parts = dotted.split(".")
+    cur = root
+    for p in parts[:-1]:
+        nxt = cur._modules.get(p)
+        if nxt is None:
+            nxt = _Node()
+            cur.add_module(p, nxt)
+        cur = nxt
+    cur.add_module(parts[-1], leaf)
+
+
+class HighResolutionNet(nn.Module):
+    CIN = 3                  # models/seg_hrnet.py:265
+    NUM_KEYPOINTS = 32       # models/seg_hrnet.py:324
+
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        cin = int(kwargs.pop("cin", self.CIN))
+        k = int(kwargs.pop("num_keypoints", self.NUM_KEYPOINTS))
+        self._cin, self._k = cin, k
+        self._cfg_struct = _cfg_struct(config, cin, k)
+        object.__setattr__(self, "_rt", _Runtime(self._cfg_struct))
+        self._descs = self._rt.conv_descs()
+        for d in self._descs:
+            conv = nn.Conv2d(d["cin"], d["cout"], d["k"], d["stride"], (d["k"] - 1) // 2, bias=d["has_bias"])
+            _place(self, d["name"], conv)
+            if d["bn"]:
+                _place(self, d["bn"], nn.BatchNorm2d(d["cout"], momentum=BN_MOMENTUM))
+        self.eval()
+
+    # ---- reference API -------------------------------------------------------------------------
+    def init_weights(self, pretrained=""):
+        logger.info("=> init weights from normal distribution")
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, std=0.001)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if os.path.isfile(pretrained):
+            # weights_only: a checkpoint is data, nothing in it is executed
+            pretrained_dict = torch.load(pretrained, map_location="cpu", weights_only=True)
+            logger.info("=> loading pretrained model {}".format(pretrained))
+            model_dict = self.state_dict()
+            model_dict.update({k: v for k, v in pretrained_dict.items() if k in model_dict})
+            self.load_state_dict(model_dict)
+
+    def forward(self, x0: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise RuntimeError("HighResolutionNet (MI355X path) is inference-only: call .eval() "
+                               "(the reference callers do, val.py:95 / demo.py:80)")
+        return self._rt.forward(self, x0)
+
+    # ---- extras of the MI355X path ---------------------------------------------------------------
+    @property
+    def num_keypoints(self):
+        return self._k
+
+    def flops_per_crop(self, h: int, w: int) -> float:
+        return self._rt.flops_per_crop(h, w)
+
+    def launch_count(self) -> int:
+        return self._rt.launch_count()
+
+    def taps(self, x0: torch.Tensor) -> dict:
+        """Debug: run a forward keeping every intermediate; returns {name: f32 NCHW tensor}."""
+        return self._rt.taps(self, x0)
+
+    def _replicate_for_data_parallel(self):
+        r = super()._replicate_for_data_parallel()
+        object.__setattr__(r, "_rt", self._rt)
+        return r
+
+
+class _Runtime:
+    """One libesahrnet handle per device + caller-owned workspace tensors."""
+
+    def __init__(self, cfg_struct):
+        self.cfg = cfg_struct
+        self.lib = _lib.lib()
+        self.handles = {}        # device index -> (handle, weight-version key)
+        self.ws = {}             # (device, n, h, w, keep) -> uint8 tensor
+        self._probe = self._create(-1)
+
+    def _create(self, device):
+        h = C.c_void_p()
+        _lib.check(self.lib.esahrnet_create(C.byref(self.cfg), max(device, 0), C.byref(h)))
+        return h
+
+    def __del__(self):
+        try:
+            for h, _ in self.handles.values():
+                self.lib.esahrnet_destroy(h)
+            self.lib.esahrnet_destroy(self._probe)
+        except Exception:
+            pass
+
+    def conv_descs(self):
+        out = []
+        for i in range(self.lib.esahrnet_conv_count(self._probe)):
+            d = _lib.ConvDesc()
+            _lib.check(self.lib.esahrnet_conv_desc_get(self._probe, i, C.byref(d)))
+            out.append(dict(name=d.name.decode(), bn=d.bn.decode(), cin=d.cin, cout=d.cout, k=d.k,
+                            stride=d.stride, has_bias=bool(d.has_bias), relu=bool(d.relu)))
+        return out
+
+    def flops_per_crop(self, h, w):
+        f = C.c_double()
+        _lib.check(self.lib.esahrnet_flops_per_crop(self._probe, h, w, C.byref(f)))
+        return f.value
+
+    def launch_count(self):
+        return self.lib.esahrnet_launch_count(self._probe)
+
+    @staticmethod
+    def _version_key(module):
+        return tuple(t._version for t in module.state_dict(keep_vars=True).values()) + \
+            tuple(id(t) for t in module.parameters())
+
+    def _handle_for(self, module, device):
+        key = self._version_key(module)
+        ent = self.handles.get(device.index)
+        if ent is not None and ent[1] == key:
+            return ent[0]
+        h = ent[0] if ent is not None else self._create(device.index)
+        sd = module.state_dict()
+        for i, d in enumerate(module._descs):
+            w, b = fold_conv(sd, d["name"], d["bn"], d["has_bias"])
+            _lib.check(self.lib.esahrnet_set_conv(h, i, w.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+        with torch.cuda.device(device):
+            _lib.check(self.lib.esahrnet_commit(h))
+        self.handles[device.index] = (h, key)
+        return h
+
+    def _check_input(self, module, x0):
+        if not isinstance(x0, torch.Tensor) or x0.dim() != 4:
+            raise ValueError("expected a 4-D tensor [N, Cin, H, W]")
+        if not x0.is_cuda:
+            raise RuntimeError("the MI355X HRNet path runs only on a GPU tensor; there is no CPU "
+                               "fallback (move the model and the crops to 'cuda')")
+        if x0.dtype != torch.float32:
+            raise TypeError(f"expected float32 crops, got {x0.dtype}")
+        if x0.shape[1] != module._cin:
+            raise ValueError(f"expected {module._cin} input channels, got {x0.shape[1]}")
+        p = next(module.parameters())
+        if p.device != x0.device:
+            raise RuntimeError(f"input on {x0.device} but parameters on {p.device}")
+        return x0.contiguous()
+
+    def _workspace(self, h, device, n, hh, ww, keep):
+        nbytes = C.c_size_t()
+        _lib.check(self.lib.esahrnet_workspace_bytes(h, n, hh, ww, C.byref(nbytes)))
+        key = (device.index, n, hh, ww, keep)
+        ws = self.ws.get(key)
+        if ws is None or ws.numel() < nbytes.value:
+            self.ws = {k: v for k, v in self.ws.items() if k[0] != device.index}   # one shape cached per device
+            ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=device)
+            self.ws[key] = ws
+        off = (-ws.data_ptr()) % 256
+        return ws, ws.data_ptr() + off, nbytes.value
+
+    def forward(self, module, x0, keep=False):
+        x = self._check_input(module, x0)
+        n, _, hh, ww = x.shape
+        dev = x.device
+        h = self._handle_for(module, dev)
+        _lib.check(self.lib.esahrnet_set_debug_keep(h, 1 if keep else 0))
+        ws, ws_ptr, ws_bytes = self._workspace(h, dev, n, hh, ww, keep)
+        heat = torch.empty((n, module._k, hh, ww), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.esahrnet_forward(h, x.data_ptr(), n, hh, ww, heat.data_ptr(), ws_ptr,
+                                                 ws_bytes, C.c_void_p(stream)))
+        ws.record_stream(torch.cuda.current_stream(dev))
+        x.record_stream(torch.cuda.current_stream(dev))
+        return heat
+
+    def taps(self, module, x0):
+        x = self._check_input(module, x0)
+        n, _, hh, ww = x.shape
+        dev = x.device
+        heat = self.forward(module, x, keep=True)
+        h = self.handles[dev.index][0]
+        _, ws_ptr, _ = self._workspace(h, dev, n, hh, ww, True)
+        out = {"heatmaps": heat}
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        buf = C.create_string_buffer(96)
+        for i in range(self.lib.esahrnet_tap_count(h)):
+            _lib.check(self.lib.esahrnet_tap_name(h, i, buf, 96))
+            name = buf.value
+            c, th, tw = C.c_int(), C.c_int(), C.c_int()
+            _lib.check(self.lib.esahrnet_tap_shape(h, name, hh, ww, C.byref(c), C.byref(th), C.byref(tw)))
+            t = torch.empty((n, c.value, th.value, tw.value), dtype=torch.float32, device=dev)
+            _lib.check(self.lib.esahrnet_tap_read(h, name, n, hh, ww, ws_ptr, t.data_ptr(), C.c_void_p(stream)))
+            out[name.decode()] = t
+        _lib.check(self.lib.esahrnet_set_debug_keep(h, 0))
+        return out
+
+
+def get_seg_model(cfg, **kwargs):
+    """models/seg_hrnet.py:495-499."""
+    model = HighResolutionNet(cfg, **kwargs)
+    pre = cfg.MODEL.PRETRAINED if hasattr(cfg, "MODEL") else cfg["MODEL"]["PRETRAINED"]
+    model.init_weights(pre)
+    return model

@@ -1,0 +1,125 @@
+/*
+ * esahrnet.h — C-ABI of libesahrnet.so: the MI355X (gfx950) HRNet keypoint-heatmap path.
+ *
+ * The reference (bonjour-l/esa-pose-estimation) has no FFI seam for this path: its seam is
+ * the torch.nn.Module protocol.  This header is therefore what a binding for
+ * the path would bind, entry point by entry point:
+ *
+ *   esahrnet_create / _conv_count / _conv_desc   <- models/seg_hrnet.py:260-340, 343-423
+ *                                                   (HighResolutionNet.__init__ and the _make_*
+ *                                                   builders: cfg -> list of Conv2d/BatchNorm2d)
+ *   esahrnet_set_conv / _commit                  <- models/seg_hrnet.py:475-493 init_weights /
+ *                                                   val.py:64-66 load_model -> load_state_dict
+ *   esahrnet_forward                             <- models/seg_hrnet.py:425-473
+ *                                                   HighResolutionNet.forward (val.py:146 call)
+ *   esahrnet_keypoints                           <- demo.py:172-185 / val.py:151-164 two-stage
+ *                                                   torch.max + inference.py:136-152 get_final
+ *                                                   (inference.py:75-94 my_taylor)
+ *
+ * Conventions: plain C types only; every function returns 0 on success, non-zero on error
+ * with a message in esahrnet_last_error() (thread-local); nothing throws across the ABI.
+ * All device buffers are CALLER-OWNED (in the Python host: torch tensors, so the caching
+ * allocator and stream semantics stay intact).  The handle owns only the packed weights.
+ * Kernels are enqueued on the stream passed in and never synchronise it.  One handle per
+ * device; calls on one handle are not re-entrant.
+ */
+#ifndef ESAHRNET_H
+#define ESAHRNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESAHRNET_MAX_BRANCHES 4
+#define ESAHRNET_ABI_VERSION 1
+
+typedef struct esahrnet_ctx* esahrnet_handle;
+typedef void* esahrnet_stream; /* hipStream_t */
+
+/* Stage table of config/default.py:39-74 as plain ints. */
+typedef struct esahrnet_cfg {
+    int32_t cin;                 /* 1 (seg_hrnet2.py:265) or 3 (seg_hrnet.py:265)            */
+    int32_t num_keypoints;       /* 11 (seg_hrnet2.py:324) or 32 (seg_hrnet.py:324)           */
+    int32_t stem_width;          /* 64 (seg_hrnet.py:265-270)                                  */
+    int32_t widths[ESAHRNET_MAX_BRANCHES];          /* NUM_CHANNELS of STAGE4: 32,64,128,256   */
+    int32_t blocks[4][ESAHRNET_MAX_BRANCHES];       /* NUM_BLOCKS per stage (stage1 uses [0][0]) */
+    int32_t modules[4];          /* NUM_MODULES per stage (stage1 entry unused)                */
+    int32_t final_conv_kernel;   /* FINAL_CONV_KERNEL, must be 1 (config/default.py:43)        */
+} esahrnet_cfg;
+
+/* One Conv2d of the reference module tree, by its state_dict prefix. */
+typedef struct esahrnet_conv_desc {
+    char name[96];               /* e.g. "stage3.0.fuse_layers.2.0.1.0" (conv: name + ".weight") */
+    char bn[96];                 /* partner BatchNorm2d prefix, "" if none (output_layer.0)    */
+    int32_t cin, cout, k, stride;
+    int32_t has_bias;            /* conv carries its own bias (last_layer.0/3, output_layer.0) */
+    int32_t relu;                /* a ReLU follows conv(+BN) directly                           */
+} esahrnet_conv_desc;
+
+const char* esahrnet_last_error(void);
+int esahrnet_abi_version(void);
+
+/* Build the static plan for a stage table.  `device` is the HIP device ordinal the weights
+ * will live on; nothing touches the device until esahrnet_commit. */
+int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out);
+int esahrnet_destroy(esahrnet_handle h);
+
+int esahrnet_conv_count(esahrnet_handle h);
+int esahrnet_conv_desc_get(esahrnet_handle h, int index, esahrnet_conv_desc* out);
+
+/* Hand over one convolution with BatchNorm ALREADY FOLDED (eval mode, eps 1e-5):
+ * w: host f32 [cout][cin][k][k], b: host f32 [cout] (never NULL). */
+int esahrnet_set_conv(esahrnet_handle h, int index, const float* w, const float* b);
+/* Pack (split-bf16, MFMA fragment order) and upload every convolution.  Synchronous. */
+int esahrnet_commit(esahrnet_handle h);
+
+/* Bytes of caller-owned device scratch esahrnet_forward needs for a batch of n crops of h x w. */
+int esahrnet_workspace_bytes(esahrnet_handle h, int n, int height, int width, size_t* bytes);
+
+/* x_dev: f32 [n][cin][height][width] NCHW contiguous (already normalised, data_load_val.py:86).
+ * heat_dev: f32 [n][K][height][width] NCHW, fully overwritten.  x_dev is not modified. */
+int esahrnet_forward(esahrnet_handle h, const void* x_dev, int n, int height, int width,
+                     void* heat_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream);
+
+/* heat_dev: f32 [n][k][height][width] -> kp_dev: f32 [n][k][3] = (x, y, peak):
+ * first-occurrence arg-max, log-quadratic sub-pixel refine, raw peak value. */
+int esahrnet_keypoints(const void* heat_dev, int n, int k, int height, int width,
+                       void* kp_dev, esahrnet_stream stream);
+
+/* ---- introspection / per-operator entry points (used by the parity tests) ------------- */
+
+/* Algorithmic (direct-convolution) FLOPs of one forward of one crop: 2 * MACs of every conv. */
+int esahrnet_flops_per_crop(esahrnet_handle h, int height, int width, double* flops);
+/* Number of kernel launches one forward enqueues. */
+int esahrnet_launch_count(esahrnet_handle h);
+/* Names of the intermediate tensors that can be dumped ("stem2", "layer1", "stage3.1", ...). */
+int esahrnet_tap_count(esahrnet_handle h);
+int esahrnet_tap_name(esahrnet_handle h, int index, char* out, size_t cap);
+/* keep != 0: every intermediate tensor gets its own workspace region (no recycling) so that
+ * esahrnet_tap_read can be used after a forward; changes esahrnet_workspace_bytes. */
+int esahrnet_set_debug_keep(esahrnet_handle h, int keep);
+/* After a forward on (n,height,width) with the same workspace: convert intermediate tensor
+ * `name` from the internal split-bf16 NHWC layout to f32 NCHW [n][c][th][tw] in out_dev. */
+int esahrnet_tap_shape(esahrnet_handle h, const char* name, int height, int width,
+                       int* c, int* th, int* tw);
+int esahrnet_tap_read(esahrnet_handle h, const char* name, int n, int height, int width,
+                      const void* ws_dev, void* out_dev, esahrnet_stream stream);
+
+/* Stand-alone convolution on f32 NCHW device tensors through the same MFMA kernels:
+ * y = [relu]( conv_{k,stride,pad=(k-1)/2}(x; w) + b [+ res] ).  w,b are HOST pointers
+ * (packed and uploaded on the spot; synchronous; test use only). */
+int esahrnet_op_conv(const void* x_dev, int n, int cin, int height, int width,
+                     const float* w, const float* b, int cout, int k, int stride, int relu,
+                     const void* res_dev, void* y_dev, esahrnet_stream stream);
+/* y = [relu]( sum_i up_bilinear_align_corners_false(x_i -> (height,width)) ), f32 NCHW. */
+int esahrnet_op_fuse(const void* const* xs_dev, const int* hs, const int* ws, int nterms,
+                     int n, int c, int height, int width, int relu, void* y_dev,
+                     esahrnet_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESAHRNET_H */

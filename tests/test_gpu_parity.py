@@ -1,0 +1,279 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path through the C-ABI vs the
+CPU oracle on the same seeded inputs, vs the golden fixtures produced by the real reference, and
+size-independent properties at BASELINE.json's full batch size.
+
+Tolerance: BASELINE.json's north_star asks heatmap L_inf <= 1e-3 abs (fp32) against the
+reference CPU forward.  The split-bf16 arithmetic is expected at ~1e-5 (oracle/emulate_split_bf16.py),
+so the tests assert the contractual 1e-3 AND a tighter 2e-4 regression guard."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # contractual (north_star)
+GUARD = 2e-4        # regression guard for the split-bf16 kernels
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (torch.cuda.is_available() is False)")
+    from esa_pose_estimation_amd import _lib, config, inference, seg_hrnet, seg_hrnet2, synth
+    from oracle import hrnet_ref, keypoints_ref
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    return dict(lib=_lib.lib(), L=_lib, config=config, inference=inference, seg_hrnet=seg_hrnet,
+                seg_hrnet2=seg_hrnet2, synth=synth, hrnet_ref=hrnet_ref, kref=keypoints_ref)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------- operators
+CONV_CASES = [
+    # n, cin, cout, h, w, k, stride, relu, res
+    (2, 32, 32, 32, 32, 3, 1, True, True),
+    (1, 64, 64, 16, 48, 3, 1, True, False),
+    (1, 32, 64, 32, 32, 3, 2, True, False),
+    (2, 64, 64, 34, 30, 3, 2, False, False),      # odd-ish sizes, stride 2, partial tiles
+    (1, 128, 32, 16, 16, 1, 1, False, False),
+    (1, 96, 480, 8, 8, 1, 1, False, True),
+    (1, 48, 11, 20, 24, 1, 1, True, False),       # channel padding on both sides
+    (1, 8, 16, 18, 22, 3, 1, True, True),         # tiny widths
+    (3, 256, 256, 16, 16, 3, 1, True, True),      # deepest branch shape
+    (1, 32, 32, 7, 5, 3, 1, False, False),        # image smaller than a tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_op_conv_matches_torch_cpu(env, case):
+    n, cin, cout, h, w, k, stride, relu, use_res = case
+    synth, lib, L = env["synth"], env["lib"], env["L"]
+    x = torch.from_numpy(synth.normal("opx", 1, (n, cin, h, w)))
+    wt = torch.from_numpy(synth.normal("opw", 2, (cout, cin, k, k), float(np.sqrt(1.0 / (cin * k * k)))))
+    b = torch.from_numpy(synth.normal("opb", 3, (cout,), 0.1))
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=(k - 1) // 2)
+    res = None
+    if use_res:
+        res = torch.from_numpy(synth.normal("opr", 4, tuple(ref.shape)))
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    xd = x.cuda()
+    rd = res.cuda() if use_res else None
+    y = torch.full(tuple(ref.shape), float("nan"), device="cuda")
+    wn, bn = wt.numpy(), b.numpy()
+    L.check(lib.esahrnet_op_conv(xd.data_ptr(), n, cin, h, w, wn.ctypes.data_as(C.c_void_p),
+                                 bn.ctypes.data_as(C.c_void_p), cout, k, stride, int(relu),
+                                 rd.data_ptr() if use_res else None, y.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err <= 5e-5, err
+
+
+def test_op_fuse_matches_torch_cpu(env):
+    synth, lib, L = env["synth"], env["lib"], env["L"]
+    n, c, h, w = 2, 40, 24, 40
+    sizes = [(24, 40), (12, 20), (6, 10), (3, 5)]
+    xs = [torch.from_numpy(synth.normal(f"fx{i}", 5, (n, c, a, b))) for i, (a, b) in enumerate(sizes)]
+    ref = xs[0].clone()
+    for t in xs[1:]:
+        ref = ref + F.interpolate(t, size=(h, w), mode="bilinear", align_corners=False)
+    ref = F.relu(ref)
+    xd = [t.cuda() for t in xs]
+    ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in xd])
+    hs = (C.c_int * 4)(*[s[0] for s in sizes])
+    ws = (C.c_int * 4)(*[s[1] for s in sizes])
+    y = torch.empty((n, c, h, w), device="cuda")
+    L.check(lib.esahrnet_op_fuse(ptrs, hs, ws, 4, n, c, h, w, 1, y.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    assert (y.cpu() - ref).abs().max().item() <= 5e-5
+
+
+# ------------------------------------------------------------------------------------- full net
+def _build(env, variant, widths, seed):
+    mod = env[variant]
+    net = mod.get_seg_model(env["config"].make_config(widths=widths))
+    sd = env["synth"].make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=seed)
+    net.load_state_dict(sd, strict=True)
+    return net.cuda().eval(), sd
+
+
+GOLDEN = ["tiny_hrnet2_64", "tiny_hrnet_64", "w32_hrnet2_128", "w32_hrnet2_256", "w32_hrnet_256"]
+
+
+@pytest.mark.parametrize("tag", GOLDEN)
+def test_full_net_matches_reference_golden(env, golden_dir, tag):
+    """HIP forward vs the output of the REAL reference model (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, tag + ".npz"), allow_pickle=False)
+    variant = str(g["variant"])
+    net, sd = _build(env, variant, tuple(int(v) for v in g["widths"]), int(g["seed"]))
+    cin = 3 if variant == "seg_hrnet" else 1
+    x = env["synth"].make_crops(int(g["n"]), cin, int(g["hw"]), int(g["hw"]), seed=int(g["seed"]))
+    with torch.no_grad():
+        y = net(x.cuda()).cpu().numpy()
+    s = int(g["subsample"])
+    err = np.abs(y[:, :, ::s, ::s] - g["out"]).max()
+    print(f"{tag}: Linf vs reference {err:.3e} (absmax {float(g['out_absmax']):.3f})")
+    assert np.isfinite(y).all()
+    assert err <= TOL, err
+    assert err <= GUARD, err
+    flat = y.reshape(y.shape[0], y.shape[1], -1)
+    assert np.array_equal(flat.argmax(-1), g["plane_argmax"])
+
+
+def test_intermediate_tensors_match_oracle(env):
+    """Every named intermediate (stem, layer1, each stage's branches, head) vs the oracle."""
+    net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 4)
+    x = env["synth"].make_crops(1, 1, 96, 64, seed=4)
+    taps_ref = {}
+    with torch.no_grad():
+        out_ref = env["hrnet_ref"].forward(sd, env["hrnet_ref"].default_cfg(1, 11), x, taps_ref)
+        taps = net.taps(x.cuda())
+    torch.cuda.synchronize()
+    worst = 0.0
+    for name, ref in taps_ref.items():
+        got = taps[name].cpu()
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        err = (got - ref).abs().max().item()
+        worst = max(worst, err)
+        assert err <= GUARD, (name, err)
+    assert (taps["heatmaps"].cpu() - out_ref).abs().max().item() <= GUARD
+    print(f"worst intermediate Linf {worst:.3e} over {len(taps_ref)} tensors")
+
+
+@pytest.mark.parametrize("hw", [(48, 80), (40, 56), (16, 16), (18, 34)])
+def test_odd_shapes_match_oracle(env, hw):
+    net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 6)
+    x = env["synth"].make_crops(2, 1, hw[0], hw[1], seed=6)
+    with torch.no_grad():
+        ref = env["hrnet_ref"].forward(sd, env["hrnet_ref"].default_cfg(1, 11), x)
+        y = net(x.cuda()).cpu()
+    assert (y - ref).abs().max().item() <= GUARD
+
+
+def test_batch32_properties_and_golden(env, golden_dir):
+    """BASELINE config 2 (W32, 256x256, batch 32): crops are independent, so every sample of the
+    batch must equal its own batch-1 forward bit for bit, sample 0 must match the reference's
+    golden output, and the input must come back untouched."""
+    g = np.load(os.path.join(golden_dir, "w32_hrnet2_256.npz"), allow_pickle=False)
+    net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 0)
+    synth = env["synth"]
+    x0 = synth.make_crops(1, 1, 256, 256, seed=0)
+    rest = synth.make_crops(31, 1, 256, 256, seed=123)
+    x = torch.cat([x0, rest]).cuda()
+    xc = x.clone()
+    with torch.no_grad():
+        y = net(x)
+        y_single = [net(x[i:i + 1]) for i in (0, 7, 31)]
+    torch.cuda.synchronize()
+    assert torch.equal(x, xc)
+    for i, ys in zip((0, 7, 31), y_single):
+        assert torch.equal(y[i:i + 1], ys), i
+    err = np.abs(y[0:1].cpu().numpy() - g["out"]).max()
+    assert err <= GUARD, err
+    # permutation equivariance over the batch
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(0)).cuda()
+    with torch.no_grad():
+        yp = net(x[perm])
+    assert torch.equal(yp, y[perm])
+
+
+def test_state_dict_roundtrip_and_reload(env):
+    """load_state_dict of new weights must change the output (weights are re-folded), and a
+    strict round trip through state_dict() must reproduce it."""
+    net, sd = _build(env, "seg_hrnet2", (8, 16, 32, 64), 8)
+    x = env["synth"].make_crops(1, 1, 32, 32, seed=8).cuda()
+    with torch.no_grad():
+        y1 = net(x).clone()
+        saved = {k: v.clone() for k, v in net.state_dict().items()}
+        sd2 = env["synth"].make_state_dict({k: v.shape for k, v in saved.items()}, seed=9)
+        net.load_state_dict(sd2, strict=True)
+        y2 = net(x).clone()
+        net.load_state_dict(saved, strict=True)
+        y3 = net(x).clone()
+    assert not torch.equal(y1, y2)
+    assert torch.equal(y1, y3)
+
+
+def test_graph_capture_replays(env):
+    """The library only enqueues on the caller's stream and never synchronises, so a forward can
+    be captured in a HIP graph by the host (torch.cuda.graph) and replayed."""
+    net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 0)
+    x = env["synth"].make_crops(2, 1, 64, 64, seed=1).cuda()
+    with torch.no_grad():
+        want = net(x).clone()
+        static_x = x.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            net(static_x)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = net(static_x)
+        static_x.copy_(x)
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+
+
+def test_errors(env):
+    net, _ = _build(env, "seg_hrnet2", (8, 16, 32, 64), 1)
+    with pytest.raises(Exception):
+        net(torch.zeros(1, 1, 30, 31, device="cuda"))        # odd width
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 32, 32, device="cuda"))        # wrong channel count
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 1, 32, 32))                       # CPU tensor: no fallback
+    with pytest.raises(TypeError):
+        net(torch.zeros(1, 1, 32, 32, device="cuda", dtype=torch.float16))
+    net.train()
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 1, 32, 32, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------- keypoints
+@pytest.mark.parametrize("tag", ["keypoints_gauss", "keypoints_adversarial", "keypoints_randn"])
+def test_keypoints_match_reference_golden(env, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, tag + ".npz"), allow_pickle=False)
+    hm = torch.from_numpy(g["hm"]).cuda()
+    kp = env["inference"].heatmaps_to_keypoints(hm).cpu().numpy()
+    assert np.array_equal(kp[..., 2], g["caller_max"])                 # raw peak, bit-exact
+    # refined coordinates: the reference evaluates the offset in Python float64 and adds it into
+    # a float32 array; the kernel does the same in f64 -> allow 1 ulp-ish of f32 at 64 px
+    assert np.abs(kp[..., :2] - g["refined"]).max() <= 2e-5
+    # integer arg-max (undo is impossible, so compare through get_max_preds)
+    preds, maxvals = env["inference"].get_max_preds(g["hm"])
+    assert np.array_equal(preds, g["coords"])
+    assert np.array_equal(maxvals[..., 0], g["maxvals"])
+
+
+def test_keypoints_full_size_vs_oracle(env):
+    """K=11 planes of 256x256 for a 32-crop batch: arg-max bit-exact, refine within 2e-5."""
+    hm = env["synth"].make_gaussian_heatmaps(32, 11, 256, 256, seed=3)
+    kp = env["inference"].heatmaps_to_keypoints(hm.cuda()).cpu().numpy()
+    ref = env["kref"].heatmaps_to_keypoints(hm.numpy())
+    assert np.array_equal(kp[..., 2], ref[..., 2])
+    assert np.abs(kp[..., :2] - ref[..., :2]).max() <= 2e-5
+    # get_final drop-in (batch-1 contract of inference.py:148)
+    one = env["inference"].get_final(hm[:1].numpy(), None)
+    assert np.abs(one - ref[0, :, :2]).max() <= 2e-5
+
+
+def test_end_to_end_keypoints_on_network_output(env):
+    net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 0)
+    x = env["synth"].make_crops(4, 1, 128, 128, seed=2)
+    with torch.no_grad():
+        heat = net(x.cuda())
+        kp = env["inference"].heatmaps_to_keypoints(heat).cpu().numpy()
+        ref_heat = env["hrnet_ref"].forward(sd, env["hrnet_ref"].default_cfg(1, 11), x).numpy()
+    # keypoints of the HIP heatmaps by the HIP kernel == oracle post-processing of the same maps
+    ref_same = env["kref"].heatmaps_to_keypoints(heat.cpu().numpy())
+    assert np.abs(kp - ref_same).max() <= 2e-5
+    assert np.abs(heat.cpu().numpy() - ref_heat).max() <= GUARD
