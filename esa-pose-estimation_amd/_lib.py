@@ -23,6 +23,11 @@ class ConvDesc(C.Structure):
                 ("has_bias", C.c_int32), ("relu", C.c_int32)]
 
 
+class OpDesc(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("label", C.c_char * 96), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 class EsaHrnetError(RuntimeError):
     pass
 
@@ -44,6 +49,9 @@ _SIGS = {
     "esahrnet_keypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "esahrnet_flops_per_crop": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "esahrnet_launch_count": (C.c_int, [C.c_void_p]),
+    "esahrnet_op_desc_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(OpDesc)]),
+    "esahrnet_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_float)]),
     "esahrnet_tap_count": (C.c_int, [C.c_void_p]),
     "esahrnet_tap_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),
     "esahrnet_set_debug_keep": (C.c_int, [C.c_void_p, C.c_int]),
@@ -73,6 +81,10 @@ def lib():
         raise EsaHrnetError(
             f"{LIB_PATH} is missing — build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for this path.")
+    # torch's ROCm wheel bundles its own libamdhip64.so.7; the process must have ONE HIP runtime and
+    # it has to be the one torch's allocator/streams live in, so torch is loaded first and
+    # libesahrnet.so's NEEDED libamdhip64.so.7 then resolves to the already-loaded copy.
+    import torch  # noqa: F401
     l = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(l, name)           # AttributeError = header/library mismatch: fail loudly

@@ -503,8 +503,9 @@ int esahrnet_workspace_bytes(esahrnet_handle h, int n, int height, int width, si
     return 0;
 }
 
-int esahrnet_forward(esahrnet_handle h, const void* x_dev, int n, int height, int width,
-                     void* heat_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream_) {
+static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, int width,
+                       void* heat_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream_,
+                       hipEvent_t* events) {
     if (!h || !x_dev || !heat_dev || !ws_dev) return fail("forward: null argument");
     if (!h->committed) return fail("forward: esahrnet_commit has not been called");
     if (plan_shape(*h, n, height, width)) return 1;
@@ -514,6 +515,8 @@ int esahrnet_forward(esahrnet_handle h, const void* x_dev, int n, int height, in
     char* ws = static_cast<char*>(ws_dev);
     const ShapePlan& sp = h->sp;
     auto T = [&](int t) { return ws + h->tensors[t].off; };
+    int op_index = 0;
+    if (events && hipEventRecord(events[0], stream) != hipSuccess) return fail("forward: hipEventRecord failed");
     for (const Op& o : h->ops) {
         int rc = 0;
         switch (o.kind) {
@@ -565,6 +568,78 @@ int esahrnet_forward(esahrnet_handle h, const void* x_dev, int n, int height, in
             }
         }
         if (rc) return fail("forward: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        ++op_index;
+        if (events && hipEventRecord(events[op_index], stream) != hipSuccess) return fail("forward: hipEventRecord failed");
+    }
+    return 0;
+}
+
+int esahrnet_forward(esahrnet_handle h, const void* x_dev, int n, int height, int width,
+                     void* heat_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream) {
+    return run_forward(h, x_dev, n, height, width, heat_dev, ws_dev, ws_bytes, stream, nullptr);
+}
+
+int esahrnet_forward_timed(esahrnet_handle h, const void* x_dev, int n, int height, int width,
+                           void* heat_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream,
+                           float* ms_out) {
+    if (!h || !ms_out) return fail("forward_timed: null argument");
+    const size_t nops = h->ops.size();
+    std::vector<hipEvent_t> ev(nops + 1, nullptr);
+    int rc = 0;
+    for (size_t i = 0; i <= nops && !rc; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) rc = fail("forward_timed: hipEventCreate failed");
+    if (!rc) rc = run_forward(h, x_dev, n, height, width, heat_dev, ws_dev, ws_bytes, stream, ev.data());
+    if (!rc && hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) rc = fail("forward_timed: stream sync failed");
+    for (size_t i = 0; i < nops && !rc; ++i)
+        if (hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]) != hipSuccess) rc = fail("forward_timed: hipEventElapsedTime failed");
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    return rc;
+}
+
+int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int width, esahrnet_op_desc* out) {
+    if (!h || !out || index < 0 || index >= (int)h->ops.size()) return fail("op_desc_get: bad argument");
+    if (check_shape(*h, n, height, width)) return 1;
+    std::vector<int> lh, lw;
+    level_dims(*h, height, width, lh, lw);
+    memset(out, 0, sizeof *out);
+    const Op& o = h->ops[index];
+    auto tbytes = [&](int t) { const Tensor& x = h->tensors[t]; return (double)n * lh[x.level] * lw[x.level] * x.Cp * 4.0; };
+    switch (o.kind) {
+        case OP_STEM: {
+            const ConvSpec& s = h->specs[h->spec_stem];
+            snprintf(out->kernel, sizeof out->kernel, "stem_kernel");
+            snprintf(out->label, sizeof out->label, "%s", s.name.c_str());
+            out->flops = 2.0 * n * height * width * s.cout * s.cin * 9;
+            out->bytes = (double)n * height * width * s.cin * 4 + tbytes(o.out);
+            break;
+        }
+        case OP_CONV: {
+            const DevConv& d = h->dconvs[o.dconv];
+            const ConvSpec& s = h->specs[d.spec];
+            const Tensor& to = h->tensors[o.out];
+            snprintf(out->kernel, sizeof out->kernel, "conv_mfma<%d,%d>", s.k, s.stride);
+            if (d.c0 != 0 || d.c1 != s.cin) snprintf(out->label, sizeof out->label, "%s[:, %d:%d]", s.name.c_str(), d.c0, d.c1);
+            else snprintf(out->label, sizeof out->label, "%s", s.name.c_str());
+            out->flops = 2.0 * n * lh[to.level] * lw[to.level] * s.cout * (d.c1 - d.c0) * s.k * s.k;
+            out->bytes = tbytes(o.in) + tbytes(o.out) + (o.res >= 0 ? tbytes(o.res) : 0.0) +
+                         (double)esa::packed_weight_bytes(d.coutp, d.cinp, s.k);
+            break;
+        }
+        case OP_FUSE: {
+            snprintf(out->kernel, sizeof out->kernel, "fuse_kernel");
+            snprintf(out->label, sizeof out->label, "fuse -> %s", h->tensors[o.out].tap.c_str());
+            out->bytes = tbytes(o.out);
+            for (int i = 0; i < o.nterms; ++i) out->bytes += tbytes(o.terms[i]);
+            break;
+        }
+        case OP_FINAL: {
+            const ConvSpec& s = h->specs[h->spec_final];
+            snprintf(out->kernel, sizeof out->kernel, "final_kernel");
+            snprintf(out->label, sizeof out->label, "%s", s.name.c_str());
+            out->flops = 2.0 * n * height * width * s.cout * s.cin * 9;
+            out->bytes = tbytes(o.in) + (double)n * height * width * (h->cfg.cin + s.cout) * 4;
+            break;
+        }
     }
     return 0;
 }

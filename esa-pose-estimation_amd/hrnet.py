@@ -132,6 +132,11 @@ class HighResolutionNet(nn.Module):
     def launch_count(self) -> int:
         return self._rt.launch_count()
 
+    def forward_timed(self, x0: torch.Tensor):
+        """Measurement: one forward with every launch bracketed by HIP events on the current
+        stream -> (heatmaps, [dict(kernel, label, ms, flops, bytes)] per launch)."""
+        return self._rt.forward_timed(self, x0)
+
     def taps(self, x0: torch.Tensor) -> dict:
         """Debug: run a forward keeping every intermediate; returns {name: f32 NCHW tensor}."""
         return self._rt.taps(self, x0)
@@ -244,6 +249,28 @@ class _Runtime:
         ws.record_stream(torch.cuda.current_stream(dev))
         x.record_stream(torch.cuda.current_stream(dev))
         return heat
+
+    def forward_timed(self, module, x0):
+        x = self._check_input(module, x0)
+        n, _, hh, ww = x.shape
+        dev = x.device
+        h = self._handle_for(module, dev)
+        _lib.check(self.lib.esahrnet_set_debug_keep(h, 0))
+        ws, ws_ptr, ws_bytes = self._workspace(h, dev, n, hh, ww, False)
+        heat = torch.empty((n, module._k, hh, ww), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        nops = self.lib.esahrnet_launch_count(h)
+        ms = (C.c_float * nops)()
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.esahrnet_forward_timed(h, x.data_ptr(), n, hh, ww, heat.data_ptr(), ws_ptr,
+                                                       ws_bytes, C.c_void_p(stream), ms))
+        ops = []
+        for i in range(nops):
+            d = _lib.OpDesc()
+            _lib.check(self.lib.esahrnet_op_desc_get(h, i, n, hh, ww, C.byref(d)))
+            ops.append(dict(kernel=d.kernel.decode(), label=d.label.decode(), ms=float(ms[i]),
+                            flops=d.flops, bytes=d.bytes))
+        return heat, ops
 
     def taps(self, module, x0):
         x = self._check_input(module, x0)

@@ -95,6 +95,20 @@ int esahrnet_keypoints(const void* heat_dev, int n, int k, int height, int width
 int esahrnet_flops_per_crop(esahrnet_handle h, int height, int width, double* flops);
 /* Number of kernel launches one forward enqueues. */
 int esahrnet_launch_count(esahrnet_handle h);
+/* One kernel launch of the forward plan, for measurement (bench.py roofline leg). */
+typedef struct esahrnet_op_desc {
+    char kernel[64];             /* kernel template instance, e.g. "conv_mfma<3,1,16,2>"        */
+    char label[96];              /* reference layer it implements, e.g. "stage4.0.branches.3.1.conv2" */
+    double flops;                /* algorithmic FLOPs (2*MAC of the direct convolution) for n crops */
+    double bytes;                /* compulsory HBM bytes of this launch: inputs + outputs + weights */
+} esahrnet_op_desc;
+int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int width,
+                         esahrnet_op_desc* out);
+/* Same as esahrnet_forward but brackets every launch with hipEvents ON `stream` and returns the
+ * per-launch durations in milliseconds (ms_out[esahrnet_launch_count]).  Synchronises `stream`. */
+int esahrnet_forward_timed(esahrnet_handle h, const void* x_dev, int n, int height, int width,
+                           void* heat_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream,
+                           float* ms_out);
 /* Names of the intermediate tensors that can be dumped ("stem2", "layer1", "stage3.1", ...). */
 int esahrnet_tap_count(esahrnet_handle h);
 int esahrnet_tap_name(esahrnet_handle h, int index, char* out, size_t cap);
