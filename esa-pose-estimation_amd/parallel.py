@@ -36,8 +36,9 @@ def gather_keypoints(local_kp: torch.Tensor, n_total: int, group=None) -> torch.
     k = local_kp.shape[1]
     padded = local_kp.new_zeros((n_max, k, 3))
     padded[: hi - lo] = local_kp
-    out = local_kp.new_empty((world, n_max, k, 3))
-    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    flat = local_kp.new_empty((world * n_max, k, 3))
+    dist.all_gather_into_tensor(flat, padded.contiguous(), group=group)
+    out = flat.view(world, n_max, k, 3)
     parts = []
     for r in range(world):
         a, b = shard_bounds(n_total, world, r)
