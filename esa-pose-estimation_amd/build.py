@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libesahrnet.so")
-SOURCES = ["conv_mfma.hip", "stem.hip", "fuse.hip", "head.hip", "keypoints.hip", "layout.hip", "plan.hip"]
+SOURCES = ["conv_mfma.hip", "stem.hip", "fuse.hip", "head.hip", "head_fused.hip", "keypoints.hip", "layout.hip", "plan.hip"]
 HEADERS = ["kernels.h", "sb.h", os.path.join("..", "..", "include", "esahrnet.h")]
 
 
@@ -36,6 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+    flags += os.environ.get("ESA_HIPCC_FLAGS", "").split()       # tuning experiments only
     procs = []
     for s in SOURCES:
         o = os.path.join(objdir, s.replace(".hip", ".o"))

@@ -223,10 +223,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
                 }
-                uint2 hi, lo;
-                split4(v, hi, lo);
-                *reinterpret_cast<uint2*>(p.y + o) = hi;
-                *reinterpret_cast<uint2*>(p.y + o + 16) = lo;
+                if (p.out_f32) {
+                    const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
+                    *reinterpret_cast<f32x4*>(p.y + of) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    *reinterpret_cast<uint2*>(p.y + o) = hi;
+                    *reinterpret_cast<uint2*>(p.y + o + 16) = lo;
+                }
             }
         }
     }

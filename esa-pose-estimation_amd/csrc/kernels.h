@@ -15,6 +15,7 @@ struct ConvParams {
     int N, H, W, OH, OW;
     int Cinp, Coutp;    // multiples of 32
     int relu;
+    int out_f32;        // 0: y is SB; 1: y is plain f32 NHWC [N][OH][OW][Coutp] (head terms t_b)
 };
 // k in {1,3}, stride in {1,2}, pad = (k-1)/2.  Returns hipError_t as int.
 int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream);
@@ -55,6 +56,24 @@ struct FinalParams {
     int K, cin, Cp;
 };
 int launch_final(const FinalParams& p, hipStream_t stream);
+
+// ---- fused head: W0*x0 + sum up(t_b) + bias, ReLU, W3*(.) + bias, ReLU (head_fused.hip) ----------
+struct HeadParams {
+    const char* x0;     // SB [N][H][W][C0p]            stage-4 branch 0
+    const char* t[3];   // f32 NHWC [N][th][tw][Ctp]    W_b * x_b on branch b's grid, b = 1..3
+    char* y;            // SB [N][H][W][C3p]            last_layer[3..5] output
+    const uint4* w0;    // packed [Ctp/16][C0p/32][hi|lo][64]   (pack_conv_weights, k = 1)
+    const uint4* w3;    // packed [M3][Ctp/32][hi|lo][64]       (pack_head_w3, permuted K order)
+    const float* bias0; // f32 [Ctp]
+    const float* bias3; // f32 [C3p]
+    int N, H, W;
+    int th[3], tw[3];
+    int C0p, Ctp, C3p, K;
+};
+int launch_head(const HeadParams& p, hipStream_t stream);
+bool head_fused_supported(int H, int W, const int th[3], const int tw[3], int C0p, int K);
+size_t head_w3_bytes(int K, int Ctp);
+void pack_head_w3(const float* w, int K, int Ct, int Ctp, void* dst);
 
 // ---- arg-max + log-quadratic refine (keypoints.hip) ----------------------------------------
 int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, hipStream_t stream);

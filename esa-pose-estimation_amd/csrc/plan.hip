@@ -62,12 +62,13 @@ struct DevConv {                // one MFMA convolution launch (a ConvSpec or a 
     int spec;                   // index into specs
     int c0, c1;                 // input-channel slice of the spec
     bool use_bias;
+    bool out_f32 = false;       // output plain f32 NHWC instead of SB (head terms)
     int cinp, coutp;
     void* w = nullptr;          // device, packed
     float* bias = nullptr;      // device, f32 [coutp]
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_FUSE, OP_FINAL };
+enum OpKind { OP_STEM, OP_CONV, OP_FUSE, OP_HEAD, OP_FINAL };
 
 struct Tensor {
     int C, Cp, level;
@@ -104,6 +105,9 @@ struct esahrnet_ctx {
     std::vector<Op> ops;
     int spec_stem = -1, spec_final = -1;
     float *stem_w = nullptr, *stem_b = nullptr, *final_w = nullptr, *final_b = nullptr;
+    int spec_l0 = -1, spec_l3 = -1, head_c0 = 0;     // fused head (OP_HEAD)
+    void *head_w0 = nullptr, *head_w3 = nullptr;
+    float *head_b0 = nullptr, *head_b3 = nullptr;
     bool committed = false;
     bool keep = false;
     ShapePlan sp;
@@ -136,12 +140,12 @@ struct Builder {
         if (t < 0) return;
         c.tensors[t].last = std::max(c.tensors[t].last, op);
     }
-    // conv op on a spec (optionally a cin slice); returns the output tensor
+    // conv op on a spec (optionally a cin slice, optionally plain-f32 output); returns the output tensor
     int conv(int sp, int in, int res, bool relu, const std::string& tap = "", int c0 = 0, int c1 = -1,
-             bool use_bias = true) {
+             bool use_bias = true, bool out_f32 = false) {
         const ConvSpec& s = c.specs[sp];
         DevConv d;
-        d.spec = sp; d.c0 = c0; d.c1 = c1 < 0 ? s.cin : c1; d.use_bias = use_bias;
+        d.spec = sp; d.c0 = c0; d.c1 = c1 < 0 ? s.cin : c1; d.use_bias = use_bias; d.out_f32 = out_f32;
         d.cinp = pad32(d.c1 - d.c0); d.coutp = pad32(s.cout);
         c.dconvs.push_back(d);
         Op o;
@@ -268,18 +272,42 @@ int build_plan(esahrnet_ctx& c) {
     const int l0 = B.spec("last_layer.0", "last_layer.1", tot, tot, 1, 1, 1, true, true);
     const int l3 = B.spec("last_layer.3", "last_layer.4", tot, K, 1, 1, 1, true, true);
     c.spec_final = B.spec("output_layer.0", "", K + g.cin, K, 3, 1, 0, true, false);
-    std::vector<int> hterms;
-    int off = 0;
-    for (size_t b = 0; b < ys.size(); ++b) {
-        // the slice runs at branch b's own resolution: fix the output level of the slice conv
-        const int save = c.specs[l0].level;
-        c.specs[l0].level = 1 + (int)b;
-        hterms.push_back(B.conv(l0, ys[b], -1, false, "", off, off + pre[b], b == 0));
-        c.specs[l0].level = save;
-        off += pre[b];
+    int h3;
+    const bool fused_head = ys.size() == 4 && (pad32(pre[0]) == 32 || pad32(pre[0]) == 64);
+    if (fused_head) {
+        // t_b = W_b x_b on branch b's grid (f32 NHWC), b = 1..3; W_0, bias, ReLU, last_layer[3..5]
+        // and the up-sampling of the t_b all happen inside head_fused.hip
+        c.spec_l0 = l0; c.spec_l3 = l3; c.head_c0 = pre[0];
+        Op o; o.kind = OP_HEAD; o.in = ys[0]; o.nterms = 3;
+        int off = pre[0];
+        for (int b = 1; b < 4; ++b) {
+            const int save = c.specs[l0].level;
+            c.specs[l0].level = 1 + b;
+            o.terms[b - 1] = B.conv(l0, ys[b], -1, false, "", off, off + pre[b], false, true);
+            c.specs[l0].level = save;
+            off += pre[b];
+        }
+        o.out = B.tensor(K, 1, "head3");
+        const int idx = (int)c.ops.size();
+        c.tensors[o.out].def = idx;
+        B.use(o.in, idx);
+        for (int i = 0; i < 3; ++i) B.use(o.terms[i], idx);
+        c.ops.push_back(o);
+        h3 = o.out;
+    } else {
+        std::vector<int> hterms;
+        int off = 0;
+        for (size_t b = 0; b < ys.size(); ++b) {
+            // the slice runs at branch b's own resolution: fix the output level of the slice conv
+            const int save = c.specs[l0].level;
+            c.specs[l0].level = 1 + (int)b;
+            hterms.push_back(B.conv(l0, ys[b], -1, false, "", off, off + pre[b], b == 0));
+            c.specs[l0].level = save;
+            off += pre[b];
+        }
+        const int h0 = B.fuse(hterms, tot, 1, true, "head0");
+        h3 = B.conv(l3, h0, -1, true, "head3");
     }
-    const int h0 = B.fuse(hterms, tot, 1, true, "head0");
-    const int h3 = B.conv(l3, h0, -1, true, "head3");
     {
         Op o; o.kind = OP_FINAL; o.in = h3;
         B.use(h3, (int)c.ops.size());
@@ -366,7 +394,9 @@ void free_weights(esahrnet_ctx& c) {
         if (d.bias) (void)hipFree(d.bias);
         d.w = nullptr; d.bias = nullptr;
     }
-    for (float** p : {&c.stem_w, &c.stem_b, &c.final_w, &c.final_b})
+    for (float** p : {&c.stem_w, &c.stem_b, &c.final_w, &c.final_b, &c.head_b0, &c.head_b3})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    for (void** p : {&c.head_w0, &c.head_w3})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     c.committed = false;
 }
@@ -486,6 +516,24 @@ int esahrnet_commit(esahrnet_handle h) {
         }
         if (upload(w, reinterpret_cast<void**>(&h->final_w)) || upload(b, reinterpret_cast<void**>(&h->final_b))) return 1;
     }
+    if (h->spec_l0 >= 0) {   // fused head: W0 slice (standard pack), W3 (permuted-K pack), biases
+        const ConvSpec& s0 = h->specs[h->spec_l0];
+        const ConvSpec& s3 = h->specs[h->spec_l3];
+        const int ct = s0.cout, ctp = pad32(ct), c0 = h->head_c0, c0p = pad32(c0), c3p = pad32(s3.cout);
+        std::vector<float> w((size_t)ct * c0);
+        for (int co = 0; co < ct; ++co)
+            for (int ci = 0; ci < c0; ++ci) w[(size_t)co * c0 + ci] = s0.w[(size_t)co * s0.cin + ci];
+        packed.assign(esa::packed_weight_bytes(ctp, c0p, 1), 0);
+        esa::pack_conv_weights(w.data(), ct, c0, 1, ctp, c0p, packed.data());
+        if (upload(packed, &h->head_w0)) return 1;
+        packed.assign(esa::head_w3_bytes(s3.cout, ctp), 0);
+        esa::pack_head_w3(s3.w.data(), s3.cout, ct, ctp, packed.data());
+        if (upload(packed, &h->head_w3)) return 1;
+        std::vector<float> b0(ctp, 0.f), b3(c3p, 0.f);
+        std::copy(s0.b.begin(), s0.b.end(), b0.begin());
+        std::copy(s3.b.begin(), s3.b.end(), b3.begin());
+        if (upload(b0, reinterpret_cast<void**>(&h->head_b0)) || upload(b3, reinterpret_cast<void**>(&h->head_b3))) return 1;
+    }
     h->committed = true;
     return 0;
 }
@@ -538,8 +586,27 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 p.w = static_cast<const uint4*>(d.w); p.bias = d.bias;
                 p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level];
                 p.OH = sp.lh[to.level]; p.OW = sp.lw[to.level];
-                p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu;
+                p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu; p.out_f32 = d.out_f32;
                 rc = esa::launch_conv(p, s.k, s.stride, stream);
+                break;
+            }
+            case OP_HEAD: {
+                const Tensor& ti = h->tensors[o.in];
+                const Tensor& to = h->tensors[o.out];
+                esa::HeadParams p{};
+                p.x0 = T(o.in); p.y = T(o.out);
+                p.w0 = static_cast<const uint4*>(h->head_w0); p.w3 = static_cast<const uint4*>(h->head_w3);
+                p.bias0 = h->head_b0; p.bias3 = h->head_b3;
+                p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level];
+                for (int i = 0; i < 3; ++i) {
+                    const Tensor& tt = h->tensors[o.terms[i]];
+                    p.t[i] = T(o.terms[i]); p.th[i] = sp.lh[tt.level]; p.tw[i] = sp.lw[tt.level];
+                    p.Ctp = tt.Cp;
+                }
+                p.C0p = ti.Cp; p.C3p = to.Cp; p.K = h->cfg.num_keypoints;
+                if (!esa::head_fused_supported(p.H, p.W, p.th, p.tw, p.C0p, p.K))
+                    return fail("forward: fused head does not support this shape (%dx%d)", p.H, p.W);
+                rc = esa::launch_head(p, stream);
                 break;
             }
             case OP_FUSE: {
@@ -623,6 +690,17 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             out->flops = 2.0 * n * lh[to.level] * lw[to.level] * s.cout * (d.c1 - d.c0) * s.k * s.k;
             out->bytes = tbytes(o.in) + tbytes(o.out) + (o.res >= 0 ? tbytes(o.res) : 0.0) +
                          (double)esa::packed_weight_bytes(d.coutp, d.cinp, s.k);
+            break;
+        }
+        case OP_HEAD: {
+            const ConvSpec& s0 = h->specs[h->spec_l0];
+            const ConvSpec& s3 = h->specs[h->spec_l3];
+            const Tensor& to = h->tensors[o.out];
+            snprintf(out->kernel, sizeof out->kernel, "head_fused");
+            snprintf(out->label, sizeof out->label, "last_layer.0[:, 0:%d] + up + last_layer.3", h->head_c0);
+            out->flops = 2.0 * n * lh[to.level] * lw[to.level] * ((double)s0.cout * h->head_c0 + (double)s3.cout * s3.cin);
+            out->bytes = tbytes(o.in) + tbytes(o.out);
+            for (int i = 0; i < 3; ++i) out->bytes += tbytes(o.terms[i]);
             break;
         }
         case OP_FUSE: {

