@@ -22,18 +22,30 @@
 // LDS image of the input tile: 8 planes (k-group g = 0..3 x part hi/lo), each [IH*IW] pixels x
 // 16 B.  A wave's B-operand read (lane l -> pixel l&15, k-group l>>4) then touches 16
 // consecutive 16-B slots per plane pair, which is conflict-free for ds_read_b128's lane
-// groups when plane strides are multiples of 256 B (stride-2 convs: odd k-groups are shifted by
-// one slot so that even/odd pixels of the two k-groups in a lane group interleave).
-// The staging writes use a diagonal (pixel, chunk) -> lane map so that the 8 lanes of one
-// ds_write_b128 group hit 8 different slots while the global reads still cover whole 128-B
-// lines.
+// groups when the two planes are congruent mod 256 B (stride-2 convs: one slot apart so that
+// even/odd pixels of the two k-groups interleave).  Staging reads whole 128-B lines (8
+// consecutive lanes = the 8 pieces of one pixel) and scatters them to the 8 planes; the plane
+// skews keep those ds_write_b128 at most 2-way conflicted (see ConvCfg::plane_off).
 //
-// Pipeline.  The input tile of chunk c+1 is loaded into registers before the MFMAs of chunk c
-// and written to LDS after them (issue-early / write-late); the weight fragments of a chunk go
-// global -> LDS by DMA (global_load_lds, no registers); two workgroups per CU cover each
-// other's staging phases.
+// Pipeline.  Persistent workgroups (2 per CU) walk a strided list of (image, tile, cout-tile) work
+// items.  The input tile of the NEXT (item, chunk) is loaded into registers before the MFMAs of
+// the current one and written to LDS after them (issue-early / write-late), also across item
+// boundaries, so the epilogue stores of item i overlap the staging of item i+1; the weight
+// fragments of a chunk go global -> LDS by DMA (global_load_lds, no registers) and stay resident
+// across items for single-chunk layers (Cin = 32).
 #include "kernels.h"
 #include "sb.h"
+
+// ablation switches for tuning experiments (all 1 in the shipped build)
+#ifndef ESA_DO_XLOAD
+#define ESA_DO_XLOAD 1
+#endif
+#ifndef ESA_DO_MFMA
+#define ESA_DO_MFMA 1
+#endif
+#ifndef ESA_DO_STORE
+#define ESA_DO_STORE 1
+#endif
 
 namespace esa {
 
@@ -56,7 +68,7 @@ struct ConvCfg {
     static constexpr int IH = (TH - 1) * S + KS;
     static constexpr int IW = (TW - 1) * S + KS;
     static constexpr int NPIX = IH * IW;
-    static constexpr int PLANE = ((NPIX * 16 + 16 + 255) / 256) * 256;
+    static constexpr int PLANE = ((NPIX * 16 + 128 + 255) / 256) * 256;
     static constexpr int XBYTES = 8 * PLANE;
     static constexpr int WBYTES = TAPS * MT * 2048;
     static constexpr int XUNITS = ((NPIX + 7) / 8) * 64;    // 16-B units, whole 8-pixel groups
@@ -64,14 +76,21 @@ struct ConvCfg {
     static constexpr int WUNITS = TAPS * MT * 128;
     static constexpr int WITER = (WUNITS + NTHREADS - 1) / NTHREADS;
     static constexpr int LDS_BYTES = XBYTES + WBYTES;
+    static constexpr int LO_OFF = PLANE + (S == 2 ? 64 : 16);   // plane_off(2g+1) - plane_off(2g)
+    // plane j = 2*g + part (k-group g, part hi/lo).  Skews (16-B slots) are chosen for BOTH sides:
+    //  reads  (ds_read_b128, lane groups pair k-groups {0,1} and {2,3}, one part per instruction):
+    //         stride 1 needs planes g and g^1 congruent mod 256 B; stride 2 needs them one slot apart;
+    //  writes (ds_write_b128, 8 consecutive lanes = the 8 planes of ONE pixel, i.e. one coalesced
+    //         128-B global line): want distinct slots mod 128 B -> stride 2: all 8 distinct,
+    //         stride 1: 4 distinct (2-way, hidden under the store's 13-cycle issue cost).
     __host__ __device__ static constexpr int plane_off(int j) {
-        return j * PLANE + ((S == 2 && ((j >> 1) & 1)) ? 16 : 0);
+        return j * PLANE + (S == 2 ? ((j >> 1) * 16 + (j & 1) * 64) : (((j >> 2) * 2 + (j & 1)) * 16));
     }
 };
 
 template <int KS, int S, int TH, int MT>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, int tiles_x,
-                                                               int tiles_y, int ctiles) {
+                                                               int tiles_y, int ctiles, int nitems) {
     using C = ConvCfg<KS, S, TH, MT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
@@ -80,33 +99,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-
-    int b = blockIdx.x;
-    const int ct = b % ctiles; b /= ctiles;
-    const int tx = b % tiles_x; b /= tiles_x;
-    const int ty = b % tiles_y;
-    const int n = b / tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
     const int nchunks = p.Cinp >> 5;
-
-    // ---- staging maps (chunk-invariant) ----------------------------------------------------
-    // X: unit u -> 8-pixel group (u>>6), lane (r = lane>>3, t = lane&7): pixel q = grp*8 + t,
-    // 16-B chunk j = (t + r) & 7 of that pixel's 128-B channel chunk (diagonal map, see header).
-    int xg[C::XITER];      // byte offset of (pixel, j) inside this image, -1 = zero padding
     const int pix_stride = p.Cinp * 4;
-    const int jst = ((lane & 7) + (lane >> 3)) & 7;
-    const int q0 = wave * 8 + (lane & 7);                    // pixel of iteration 0; +32 per iteration
-#pragma unroll
-    for (int it = 0; it < C::XITER; ++it) {
-        const int q = q0 + it * 32;
-        const int qy = q / C::IW, qx = q - qy * C::IW;
-        const int gy = oy0 * S - C::PAD + qy, gx = ox0 * S - C::PAD + qx;
-        const bool inside = q < C::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        xg[it] = inside ? ((gy * p.W + gx) * pix_stride + jst * 16) : -1;
-    }
+
+    // Persistent workgroups: work item = (image, tile, cout tile), cout tile fastest.  Blocks b and
+    // b+8 share an XCD (round-robin dispatch), so with the remap below every XCD owns a contiguous
+    // run of items and the cout-tile siblings that re-read one input tile hit the same L2.
+    const int G = gridDim.x;
+    int item = blockIdx.x;
+    if ((G & 7) == 0) item = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+
+    // ---- staging map of the item being PREFETCHED (chunk-invariant) ---------------------------
+    // X: unit u = it*256 + tid -> pixel q = u>>3, 16-B piece j = u&7 of that pixel's 128-B channel
+    // chunk: 8 consecutive lanes read one whole 128-B line (fully coalesced).
+    int xg[C::XITER];      // byte offset of (pixel, j) inside the image, -1 = zero padding
+    const int jst = tid & 7;
+    const int q0 = tid >> 3;                                  // pixel of iteration 0; +32 per iteration
     char* xwr = xs + C::plane_off(jst) + q0 * 16;             // LDS write address, +512 per iteration
-    const char* xn = p.x + (size_t)n * p.H * p.W * pix_stride;   // 32-bit offsets inside one image
-    const uint4* wbase = p.w + (size_t)(ct * MT) * nchunks * (C::TAPS * 128);
+    const char* xn;                                           // image base of the prefetched item
+    int s_n, s_oy0, s_ox0, s_ct;
+#define ESA_DECODE(ITEM)                                                                          \
+    {                                                                                             \
+        int b_ = (ITEM);                                                                          \
+        s_ct = b_ % ctiles; b_ /= ctiles;                                                         \
+        const int tx_ = b_ % tiles_x; b_ /= tiles_x;                                              \
+        const int ty_ = b_ % tiles_y;                                                             \
+        s_n = b_ / tiles_y;                                                                       \
+        s_oy0 = ty_ * TH; s_ox0 = tx_ * TW;                                                       \
+        xn = p.x + (size_t)s_n * p.H * p.W * pix_stride;                                          \
+        _Pragma("unroll") for (int it = 0; it < C::XITER; ++it) {                                 \
+            const int q = q0 + it * 32;                                                           \
+            const int qy = q / C::IW, qx = q - qy * C::IW;                                        \
+            const int gy = s_oy0 * S - C::PAD + qy, gx = s_ox0 * S - C::PAD + qx;                 \
+            const bool inside = q < C::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;        \
+            xg[it] = inside ? ((gy * p.W + gx) * pix_stride + jst * 16) : -1;                     \
+        }                                                                                         \
+    }
 
     uint4 xr[C::XITER];
     // issue-early half of the X staging: global -> registers
@@ -114,7 +142,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
     {                                                                                             \
         _Pragma("unroll") for (int it = 0; it < C::XITER; ++it) {                                 \
             uint4 v = make_uint4(0, 0, 0, 0);                                                     \
-            if (xg[it] >= 0) v = *reinterpret_cast<const uint4*>(xn + xg[it] + (CH) * 128);       \
+            if (ESA_DO_XLOAD && xg[it] >= 0) v = *reinterpret_cast<const uint4*>(xn + xg[it] + (CH) * 128); \
             xr[it] = v;                                                                           \
         }                                                                                         \
     }
@@ -138,103 +166,146 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
         }                                                                                         \
     }
 
-    f32x4 acc[MT][C::NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < C::NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     // per-lane LDS read bases
     const int g = lane >> 4;
     const char* xrd = xs + C::plane_off(2 * g) + ((wave * C::NT * S) * C::IW + (lane & 15) * S) * 16;
     const char* wrd = wsm + lane * 16;
     constexpr int ROWS = (C::NT - 1) * S + KS;               // input rows one wave touches
-
-    ESA_PREFETCH_X(0)
-    for (int c = 0; c < nchunks; ++c) {
-        if (c) __syncthreads();          // everyone finished reading the previous chunk
-        ESA_DMA_W(c)
-        ESA_COMMIT_X()
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the W DMA of this wave has landed
-        __syncthreads();
-        if (c + 1 < nchunks) ESA_PREFETCH_X(c + 1)
-        // kx-major order: an input-row fragment (row i, column shift kx) feeds up to KS taps
-        // (output rows i-ky), so each fragment is read from LDS once instead of KS times.
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            bf16x8 wh[KS][MT], wl[KS][MT];
-#pragma unroll
-            for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    wh[ky][m] = *reinterpret_cast<const bf16x8*>(wrd + ((m * C::TAPS + ky * KS + kx) * 2 + 0) * 1024);
-                    wl[ky][m] = *reinterpret_cast<const bf16x8*>(wrd + ((m * C::TAPS + ky * KS + kx) * 2 + 1) * 1024);
-                }
-#pragma unroll
-            for (int i = 0; i < ROWS; ++i) {
-                const int off = (i * C::IW + kx) * 16;
-                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xrd + off);
-                const bf16x8 xo = *reinterpret_cast<const bf16x8*>(xrd + off + C::PLANE);
-#pragma unroll
-                for (int ky = 0; ky < KS; ++ky) {
-                    const int d = i - ky;
-                    if (d >= 0 && d % S == 0 && d / S < C::NT) {
-                        const int t = d / S;
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ky][m], xh, acc[m][t], 0, 0, 0);
-                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky][m], xo, acc[m][t], 0, 0, 0);
-                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky][m], xh, acc[m][t], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
-    }
-#undef ESA_PREFETCH_X
-#undef ESA_COMMIT_X
-#undef ESA_DMA_W
-
-    // ---- epilogue: bias, residual, ReLU, split, store -----------------------------------------
-    // D tile: column (lane&15) = pixel, rows (lane>>4)*4 + r = cout  -> 4 consecutive channels.
-    const int ox = ox0 + (lane & 15);
     const int opix = p.Coutp * 4;
+
+    if (item >= nitems) return;
+    ESA_DECODE(item)
+    ESA_PREFETCH_X(0)
+    int res_ct = -1;          // cout tile whose weights are resident in LDS (single-chunk layers)
+    bool first = true;
+    while (item < nitems) {
+        const int n = s_n, oy0 = s_oy0, ox0 = s_ox0, ct = s_ct;   // the item being computed
+        const uint4* wbase = p.w + (size_t)(ct * MT) * nchunks * (C::TAPS * 128);
+        const int next = item + G;
+        // accumulators start at bias (+ residual): the residual loads are issued here, a whole
+        // staging phase ahead of the first MFMA that consumes them, and the epilogue has no loads.
+        // D tile: column (lane&15) = pixel, rows (lane>>4)*4 + r = cout -> 4 consecutive channels.
+        const int ox = ox0 + (lane & 15);
+        f32x4 acc[MT][C::NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int co = (ct * MT + m) * 16 + g * 4;                 // first of this lane's 4 couts
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
-        const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;     // byte offset inside the pixel
+        for (int m = 0; m < MT; ++m) {
+            const int co = (ct * MT + m) * 16 + g * 4;                 // first of this lane's 4 couts
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+            const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;     // byte offset inside the pixel
 #pragma unroll
-        for (int t = 0; t < C::NT; ++t) {
-            const int oy = oy0 + wave * C::NT + t;
-            if (oy < p.OH && ox < p.OW) {
-                const size_t o = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + cofs;
-                float v[4] = {acc[m][t][0] + bv[0], acc[m][t][1] + bv[1], acc[m][t][2] + bv[2],
-                              acc[m][t][3] + bv[3]};
-                if (p.res) {
+            for (int t = 0; t < C::NT; ++t) {
+                acc[m][t] = bv;
+                const int oy = oy0 + wave * C::NT + t;
+                if (p.res && oy < p.OH && ox < p.OW) {
+                    const size_t o = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + cofs;
                     const uint2 rh = *reinterpret_cast<const uint2*>(p.res + o);
                     const uint2 rl = *reinterpret_cast<const uint2*>(p.res + o + 16);
                     float r[4];
                     join4(rh, rl, r);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += r[i];
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-                }
-                if (p.out_f32) {
-                    const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
-                    *reinterpret_cast<f32x4*>(p.y + of) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    uint2 hi, lo;
-                    split4(v, hi, lo);
-                    *reinterpret_cast<uint2*>(p.y + o) = hi;
-                    *reinterpret_cast<uint2*>(p.y + o + 16) = lo;
+                    for (int i = 0; i < 4; ++i) acc[m][t][i] += r[i];
                 }
             }
         }
+
+        for (int c = 0; c < nchunks; ++c) {
+            if (!first) __syncthreads();     // everyone finished reading the previous chunk / item
+            first = false;
+            if (nchunks > 1 || ct != res_ct) {
+                ESA_DMA_W(c)
+                res_ct = ct;
+                ESA_COMMIT_X()
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the W DMA of this wave has landed
+            } else {                         // weights already resident: nothing to wait for but X
+                ESA_COMMIT_X()
+            }
+            __syncthreads();
+            if (c + 1 < nchunks) {
+                ESA_PREFETCH_X(c + 1)
+            } else if (next < nitems) {      // cross-item pipelining: first chunk of the next item
+                ESA_DECODE(next)
+                ESA_PREFETCH_X(0)
+            }
+            // kx-major order: an input-row fragment (row i, column shift kx) feeds up to KS taps
+            // (output rows i-ky), so each fragment is read from LDS once instead of KS times.
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                bf16x8 wh[KS][MT], wl[KS][MT];
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        wh[ky][m] = *reinterpret_cast<const bf16x8*>(wrd + ((m * C::TAPS + ky * KS + kx) * 2 + 0) * 1024);
+                        wl[ky][m] = *reinterpret_cast<const bf16x8*>(wrd + ((m * C::TAPS + ky * KS + kx) * 2 + 1) * 1024);
+                    }
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i) {
+                    const int off = (i * C::IW + kx) * 16;
+                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xrd + off);
+                    const bf16x8 xo = *reinterpret_cast<const bf16x8*>(xrd + off + C::LO_OFF);
+#pragma unroll
+                    for (int ky = 0; ky < KS; ++ky) {
+                        const int d = i - ky;
+                        if (ESA_DO_MFMA && d >= 0 && d % S == 0 && d / S < C::NT) {
+                            const int t = d / S;
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ky][m], xh, acc[m][t], 0, 0, 0);
+                                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky][m], xo, acc[m][t], 0, 0, 0);
+                                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky][m], xh, acc[m][t], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue: ReLU, split, store (no loads) -------------------------------------------
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co = (ct * MT + m) * 16 + g * 4;
+            const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;
+#pragma unroll
+            for (int t = 0; t < C::NT; ++t) {
+                const int oy = oy0 + wave * C::NT + t;
+                if ((ESA_DO_STORE || acc[m][t][0] == 123.456f) && oy < p.OH && ox < p.OW) {
+                    float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
+                    if (p.relu) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    }
+                    if (p.out_f32) {
+                        const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
+                        *reinterpret_cast<f32x4*>(p.y + of) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        const size_t o = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + cofs;
+                        uint2 hi, lo;
+                        split4(v, hi, lo);
+                        *reinterpret_cast<uint2*>(p.y + o) = hi;
+                        *reinterpret_cast<uint2*>(p.y + o + 16) = lo;
+                    }
+                }
+            }
+        }
+        item = next;
     }
+#undef ESA_DECODE
+#undef ESA_PREFETCH_X
+#undef ESA_COMMIT_X
+#undef ESA_DMA_W
+}
+
+int persistent_grid(long long nitems) {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        }
+        slots = 2 * cus;                     // two workgroups per CU (80 KB LDS each)
+    }
+    return (int)(nitems < slots ? nitems : slots);
 }
 
 template <int KS, int S, int TH, int MT>
@@ -250,10 +321,11 @@ int launch_t(const ConvParams& p, hipStream_t stream) {
     }
     const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
     const int ctiles = p.Coutp / (16 * MT);
-    const long long nblk = (long long)p.N * tiles_y * tiles_x * ctiles;
-    if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTHREADS), C::LDS_BYTES, stream, p, tiles_x,
-                       tiles_y, ctiles);
+    const long long nitems = (long long)p.N * tiles_y * tiles_x * ctiles;
+    if (nitems <= 0 || nitems > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const int grid = persistent_grid(nitems);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), C::LDS_BYTES, stream, p, tiles_x,
+                       tiles_y, ctiles, (int)nitems);
     return (int)hipGetLastError();
 }
 
