@@ -88,7 +88,7 @@ struct ConvCfg {
     }
 };
 
-template <int KS, int S, int TH, int MT>
+template <int KS, int S, int TH, int MT, bool PERSIST>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, int tiles_x,
                                                                int tiles_y, int ctiles, int nitems) {
     using C = ConvCfg<KS, S, TH, MT>;
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
     // Persistent workgroups: work item = (image, tile, cout tile), cout tile fastest.  Blocks b and
     // b+8 share an XCD (round-robin dispatch), so with the remap below every XCD owns a contiguous
     // run of items and the cout-tile siblings that re-read one input tile hit the same L2.
+    // (PERSIST = false: one item per workgroup, same code with the cross-item prefetch compiled out.)
     const int G = gridDim.x;
     int item = blockIdx.x;
     if ((G & 7) == 0) item = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
             __syncthreads();
             if (c + 1 < nchunks) {
                 ESA_PREFETCH_X(c + 1)
-            } else if (next < nitems) {      // cross-item pipelining: first chunk of the next item
+            } else if (PERSIST && next < nitems) {   // cross-item pipelining: chunk 0 of the next item
                 ESA_DECODE(next)
                 ESA_PREFETCH_X(0)
             }
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
                 }
             }
         }
+        if (!PERSIST) break;
         item = next;
     }
 #undef ESA_DECODE
@@ -308,11 +310,14 @@ int persistent_grid(long long nitems) {
     return (int)(nitems < slots ? nitems : slots);
 }
 
-template <int KS, int S, int TH, int MT>
-int launch_t(const ConvParams& p, hipStream_t stream) {
+// PERSIST: persistent workgroups with cross-item prefetch and resident weights.  Measured on
+// MI355X (round 1): it pays only for single-chunk layers (Cin = 32: the weights stay in LDS for the
+// whole launch); for deeper layers its ~70 extra VGPRs cost more than the pipelining returns.
+template <int KS, int S, int TH, int MT, bool PERSIST>
+int launch_tp(const ConvParams& p, hipStream_t stream) {
     using C = ConvCfg<KS, S, TH, MT>;
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<KS, S, TH, MT>;
+    auto kern = conv_mfma_kernel<KS, S, TH, MT, PERSIST>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -323,10 +328,16 @@ int launch_t(const ConvParams& p, hipStream_t stream) {
     const int ctiles = p.Coutp / (16 * MT);
     const long long nitems = (long long)p.N * tiles_y * tiles_x * ctiles;
     if (nitems <= 0 || nitems > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    const int grid = persistent_grid(nitems);
+    const int grid = PERSIST ? persistent_grid(nitems) : (int)nitems;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), C::LDS_BYTES, stream, p, tiles_x,
                        tiles_y, ctiles, (int)nitems);
     return (int)hipGetLastError();
+}
+
+template <int KS, int S, int TH, int MT>
+int launch_t(const ConvParams& p, hipStream_t stream) {
+    if (KS == 3 && S == 1 && p.Cinp == 32) return launch_tp<KS, S, TH, MT, true>(p, stream);
+    return launch_tp<KS, S, TH, MT, false>(p, stream);
 }
 
 }  // namespace
