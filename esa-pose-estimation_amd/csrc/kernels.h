@@ -34,6 +34,18 @@ struct StemParams {
 };
 int launch_stem(const StemParams& p, hipStream_t stream);
 
+// ---- fused stem: conv1 (VALU, recomputed per tile) -> conv2 3x3 s2 (MFMA) (stem_fused.hip) -------
+struct StemFusedParams {
+    const float* x;     // f32 [N][cin][H][W]
+    char* y;            // SB [N][OH][OW][Coutp]
+    const float* w1;    // f32 [Cmid/8][cin][9][8]   (same image as StemParams::w)
+    const float* bias1; // f32 [Cmid]
+    const uint4* w2;    // packed conv2 weights (pack_conv_weights, k = 3)
+    const float* bias2; // f32 [Coutp]
+    int N, H, W, OH, OW, cin, Cmid, Coutp;
+};
+int launch_stem_fused(const StemFusedParams& p, hipStream_t stream);
+
 // ---- cross-resolution fuse: y = relu?(sum_i up(x_i)) on SB tensors (fuse.hip) ---------------
 struct FuseParams {
     const char* x[4];

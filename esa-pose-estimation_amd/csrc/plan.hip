@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -68,7 +69,7 @@ struct DevConv {                // one MFMA convolution launch (a ConvSpec or a 
     float* bias = nullptr;      // device, f32 [coutp]
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_FUSE, OP_HEAD, OP_FINAL };
+enum OpKind { OP_STEM, OP_STEMF, OP_CONV, OP_FUSE, OP_HEAD, OP_FINAL };
 
 struct Tensor {
     int C, Cp, level;
@@ -110,6 +111,7 @@ struct esahrnet_ctx {
     float *head_b0 = nullptr, *head_b3 = nullptr;
     bool committed = false;
     bool keep = false;
+    bool fuse_big = true;       // fused stem + fused head (ESAHRNET_UNFUSED=1 selects the op-by-op plan)
     ShapePlan sp;
     int max_level = 0;
 };
@@ -187,12 +189,23 @@ int build_plan(esahrnet_ctx& c) {
     const int sw = g.stem_width;
     // ---- stem (seg_hrnet.py:265-270, 426-431) ----
     c.spec_stem = B.spec("conv1", "bn1", g.cin, sw, 3, 1, 0, false, true);
-    {
+    const int spec_conv2 = B.spec("conv2", "bn2", sw, sw, 3, 2, 1, false, true);
+    int x;
+    if (c.fuse_big) {       // conv1 recomputed per tile inside the conv2 kernel (stem_fused.hip)
+        DevConv d;
+        d.spec = spec_conv2; d.c0 = 0; d.c1 = sw; d.use_bias = true;
+        d.cinp = pad32(sw); d.coutp = pad32(sw);
+        c.dconvs.push_back(d);
+        Op o; o.kind = OP_STEMF; o.dconv = (int)c.dconvs.size() - 1; o.out = B.tensor(sw, 1, "stem2");
+        c.tensors[o.out].def = 0;
+        c.ops.push_back(o);
+        x = o.out;
+    } else {
         Op o; o.kind = OP_STEM; o.out = B.tensor(sw, 0, "stem1");
         c.tensors[o.out].def = 0;
         c.ops.push_back(o);
+        x = B.conv(spec_conv2, c.ops[0].out, -1, true, "stem2");
     }
-    int x = B.conv(B.spec("conv2", "bn2", sw, sw, 3, 2, 1, false, true), c.ops[0].out, -1, true, "stem2");
     // ---- layer1 (:277, :432) ----
     int cin = sw;
     const int nb1 = g.blocks[0][0];
@@ -273,7 +286,7 @@ int build_plan(esahrnet_ctx& c) {
     const int l3 = B.spec("last_layer.3", "last_layer.4", tot, K, 1, 1, 1, true, true);
     c.spec_final = B.spec("output_layer.0", "", K + g.cin, K, 3, 1, 0, true, false);
     int h3;
-    const bool fused_head = ys.size() == 4 && (pad32(pre[0]) == 32 || pad32(pre[0]) == 64);
+    const bool fused_head = c.fuse_big && ys.size() == 4 && (pad32(pre[0]) == 32 || pad32(pre[0]) == 64);
     if (fused_head) {
         // t_b = W_b x_b on branch b's grid (f32 NHWC), b = 1..3; W_0, bias, ReLU, last_layer[3..5]
         // and the up-sampling of the t_b all happen inside head_fused.hip
@@ -429,6 +442,7 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     esahrnet_ctx* c = new esahrnet_ctx();
     c->cfg = *cfg;
     c->device = device;
+    if (const char* e = getenv("ESAHRNET_UNFUSED")) c->fuse_big = !(e[0] && e[0] != '0');
     if (build_plan(*c)) { delete c; return 1; }
     *out = c;
     return 0;
@@ -575,6 +589,18 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 rc = esa::launch_stem(p, stream);
                 break;
             }
+            case OP_STEMF: {
+                const DevConv& d = h->dconvs[o.dconv];
+                const Tensor& to = h->tensors[o.out];
+                esa::StemFusedParams p{};
+                p.x = static_cast<const float*>(x_dev); p.y = T(o.out);
+                p.w1 = h->stem_w; p.bias1 = h->stem_b;
+                p.w2 = static_cast<const uint4*>(d.w); p.bias2 = d.bias;
+                p.N = n; p.H = height; p.W = width; p.OH = sp.lh[to.level]; p.OW = sp.lw[to.level];
+                p.cin = h->cfg.cin; p.Cmid = d.cinp; p.Coutp = d.coutp;
+                rc = esa::launch_stem_fused(p, stream);
+                break;
+            }
             case OP_CONV: {
                 const DevConv& d = h->dconvs[o.dconv];
                 const ConvSpec& s = h->specs[d.spec];
@@ -678,6 +704,18 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             snprintf(out->label, sizeof out->label, "%s", s.name.c_str());
             out->flops = 2.0 * n * height * width * s.cout * s.cin * 9;
             out->bytes = (double)n * height * width * s.cin * 4 + tbytes(o.out);
+            break;
+        }
+        case OP_STEMF: {
+            const ConvSpec& s1 = h->specs[h->spec_stem];
+            const ConvSpec& s2 = h->specs[h->dconvs[o.dconv].spec];
+            const Tensor& to = h->tensors[o.out];
+            snprintf(out->kernel, sizeof out->kernel, "stem_fused");
+            snprintf(out->label, sizeof out->label, "conv1 + conv2");
+            out->flops = 2.0 * n * height * width * s1.cout * s1.cin * 9 +
+                         2.0 * n * lh[to.level] * lw[to.level] * s2.cout * s2.cin * 9;
+            out->bytes = (double)n * height * width * s1.cin * 4 + tbytes(o.out) +
+                         (double)esa::packed_weight_bytes(pad32(s2.cout), pad32(s2.cin), 3);
             break;
         }
         case OP_CONV: {

@@ -127,6 +127,24 @@ def test_full_net_matches_reference_golden(env, golden_dir, tag):
     assert np.array_equal(flat.argmax(-1), g["plane_argmax"])
 
 
+@pytest.mark.parametrize("tag", ["tiny_hrnet_64", "w32_hrnet2_128"])
+def test_unfused_plan_matches_reference_golden(env, golden_dir, tag, monkeypatch):
+    """ESAHRNET_UNFUSED=1 selects the op-by-op plan (separate stem conv1, materialised head):
+    same kernels family, different fusion — must agree with the reference just as well."""
+    monkeypatch.setenv("ESAHRNET_UNFUSED", "1")
+    g = np.load(os.path.join(golden_dir, tag + ".npz"), allow_pickle=False)
+    variant = str(g["variant"])
+    net, sd = _build(env, variant, tuple(int(v) for v in g["widths"]), int(g["seed"]))
+    cin = 3 if variant == "seg_hrnet" else 1
+    x = env["synth"].make_crops(int(g["n"]), cin, int(g["hw"]), int(g["hw"]), seed=int(g["seed"]))
+    with torch.no_grad():
+        taps = net.taps(x.cuda())
+    assert "stem1" in taps and "head0" in taps
+    y = taps["heatmaps"].cpu().numpy()
+    err = np.abs(y - g["out"]).max()
+    assert err <= GUARD, err
+
+
 def test_intermediate_tensors_match_oracle(env):
     """Every named intermediate (stem, layer1, each stage's branches, head) vs the oracle."""
     net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 4)
@@ -137,7 +155,7 @@ def test_intermediate_tensors_match_oracle(env):
         taps = net.taps(x.cuda())
     torch.cuda.synchronize()
     worst = 0.0
-    assert {"stem1", "stem2", "layer1", "stage2.0", "stage3.2", "stage4.0", "stage4.3", "head3"} <= set(taps)
+    assert {"stem2", "layer1", "stage2.0", "stage3.2", "stage4.0", "stage4.3", "head3"} <= set(taps)
     for name, ref in taps_ref.items():
         if name not in taps:          # e.g. "head0": the fused head never materialises it
             continue
