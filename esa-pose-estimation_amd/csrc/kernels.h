@@ -34,6 +34,18 @@ struct StemParams {
 };
 int launch_stem(const StemParams& p, hipStream_t stream);
 
+// ---- fused BasicBlock of the 32-channel branch (bblock32.hip) -------------------------------------
+struct BlockParams {
+    const char* x;      // SB [N][H][W][32]
+    char* y;            // SB [N][H][W][32]
+    const uint4* w1;    // packed 3x3 32->32 weights of conv1 / conv2 (pack_conv_weights)
+    const uint4* w2;
+    const float* bias1; // f32 [32]
+    const float* bias2; // f32 [32]
+    int N, H, W;
+};
+int launch_bblock32(const BlockParams& p, hipStream_t stream);
+
 // ---- fused stem: conv1 (VALU, recomputed per tile) -> conv2 3x3 s2 (MFMA) (stem_fused.hip) -------
 struct StemFusedParams {
     const float* x;     // f32 [N][cin][H][W]

@@ -69,7 +69,7 @@ struct DevConv {                // one MFMA convolution launch (a ConvSpec or a 
     float* bias = nullptr;      // device, f32 [coutp]
 };
 
-enum OpKind { OP_STEM, OP_STEMF, OP_CONV, OP_FUSE, OP_HEAD, OP_FINAL };
+enum OpKind { OP_STEM, OP_STEMF, OP_CONV, OP_BLOCK, OP_FUSE, OP_HEAD, OP_FINAL };
 
 struct Tensor {
     int C, Cp, level;
@@ -80,7 +80,8 @@ struct Tensor {
 
 struct Op {
     OpKind kind;
-    int dconv = -1;             // OP_CONV
+    int dconv = -1;             // OP_CONV / OP_STEMF / OP_BLOCK (conv1)
+    int dconv2 = -1;            // OP_BLOCK (conv2)
     int in = -1, out = -1, res = -1;
     int terms[4] = {-1, -1, -1, -1};
     int nterms = 0;
@@ -174,6 +175,22 @@ struct Builder {
         int res = x;
         const int c1 = spec(p + ".conv1", p + ".bn1", cin, cout, 3, 1, level, false, true);
         const int c2 = spec(p + ".conv2", p + ".bn2", cout, cout, 3, 1, level, false, true);
+        if (c.fuse_big && cin == cout && pad32(cin) == 32) {     // whole block in one kernel (bblock32.hip)
+            Op o;
+            o.kind = OP_BLOCK; o.in = x; o.relu = true;
+            for (int k = 0; k < 2; ++k) {
+                DevConv d;
+                d.spec = k ? c2 : c1; d.c0 = 0; d.c1 = cin; d.use_bias = true; d.cinp = 32; d.coutp = 32;
+                c.dconvs.push_back(d);
+                (k ? o.dconv2 : o.dconv) = (int)c.dconvs.size() - 1;
+            }
+            o.out = tensor(cout, level, tap);
+            const int idx = (int)c.ops.size();
+            c.tensors[o.out].def = idx;
+            use(x, idx);
+            c.ops.push_back(o);
+            return o.out;
+        }
         if (cin != cout) {
             const int d = spec(p + ".downsample.0", p + ".downsample.1", cin, cout, 1, 1, level, false, false);
             res = conv(d, x, -1, false);
@@ -616,6 +633,19 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 rc = esa::launch_conv(p, s.k, s.stride, stream);
                 break;
             }
+            case OP_BLOCK: {
+                const DevConv& d1 = h->dconvs[o.dconv];
+                const DevConv& d2 = h->dconvs[o.dconv2];
+                const Tensor& ti = h->tensors[o.in];
+                if (ti.Cp != 32 || h->tensors[o.out].Cp != 32) return fail("plan bug: bblock32 on a non-32-channel tensor");
+                esa::BlockParams p{};
+                p.x = T(o.in); p.y = T(o.out);
+                p.w1 = static_cast<const uint4*>(d1.w); p.w2 = static_cast<const uint4*>(d2.w);
+                p.bias1 = d1.bias; p.bias2 = d2.bias;
+                p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level];
+                rc = esa::launch_bblock32(p, stream);
+                break;
+            }
             case OP_HEAD: {
                 const Tensor& ti = h->tensors[o.in];
                 const Tensor& to = h->tensors[o.out];
@@ -728,6 +758,16 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             out->flops = 2.0 * n * lh[to.level] * lw[to.level] * s.cout * (d.c1 - d.c0) * s.k * s.k;
             out->bytes = tbytes(o.in) + tbytes(o.out) + (o.res >= 0 ? tbytes(o.res) : 0.0) +
                          (double)esa::packed_weight_bytes(d.coutp, d.cinp, s.k);
+            break;
+        }
+        case OP_BLOCK: {
+            const ConvSpec& s1 = h->specs[h->dconvs[o.dconv].spec];
+            const ConvSpec& s2 = h->specs[h->dconvs[o.dconv2].spec];
+            const Tensor& to = h->tensors[o.out];
+            snprintf(out->kernel, sizeof out->kernel, "bblock32");
+            snprintf(out->label, sizeof out->label, "%s + conv2", s1.name.c_str());
+            out->flops = 2.0 * n * lh[to.level] * lw[to.level] * 9.0 * ((double)s1.cout * s1.cin + (double)s2.cout * s2.cin);
+            out->bytes = tbytes(o.in) + tbytes(o.out) + 2.0 * (double)esa::packed_weight_bytes(32, 32, 3);
             break;
         }
         case OP_HEAD: {
