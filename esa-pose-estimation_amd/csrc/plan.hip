@@ -708,14 +708,27 @@ int esahrnet_forward_timed(esahrnet_handle h, const void* x_dev, int n, int heig
     if (!h || !ms_out) return fail("forward_timed: null argument");
     const size_t nops = h->ops.size();
     std::vector<hipEvent_t> ev(nops + 1, nullptr);
+    hipEvent_t nul[2] = {nullptr, nullptr};
     int rc = 0;
     for (size_t i = 0; i <= nops && !rc; ++i)
         if (hipEventCreate(&ev[i]) != hipSuccess) rc = fail("forward_timed: hipEventCreate failed");
+    for (int i = 0; i < 2 && !rc; ++i)
+        if (hipEventCreate(&nul[i]) != hipSuccess) rc = fail("forward_timed: hipEventCreate failed");
+    // the cost of an empty event bracket on this stream is measured and subtracted, so that the
+    // per-launch figures are kernel time (comparable with rocprofv3 --kernel-trace), not kernel + marker
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!rc && (hipEventRecord(nul[0], st) != hipSuccess || hipEventRecord(nul[1], st) != hipSuccess))
+        rc = fail("forward_timed: hipEventRecord failed");
     if (!rc) rc = run_forward(h, x_dev, n, height, width, heat_dev, ws_dev, ws_bytes, stream, ev.data());
-    if (!rc && hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) rc = fail("forward_timed: stream sync failed");
-    for (size_t i = 0; i < nops && !rc; ++i)
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail("forward_timed: stream sync failed");
+    float null_ms = 0.f;
+    if (!rc && hipEventElapsedTime(&null_ms, nul[0], nul[1]) != hipSuccess) rc = fail("forward_timed: hipEventElapsedTime failed");
+    for (size_t i = 0; i < nops && !rc; ++i) {
         if (hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]) != hipSuccess) rc = fail("forward_timed: hipEventElapsedTime failed");
+        ms_out[i] = ms_out[i] > null_ms ? ms_out[i] - null_ms : 0.f;
+    }
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : nul) if (e) (void)hipEventDestroy(e);
     return rc;
 }
 

@@ -105,7 +105,8 @@ typedef struct esahrnet_op_desc {
 int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int width,
                          esahrnet_op_desc* out);
 /* Same as esahrnet_forward but brackets every launch with hipEvents ON `stream` and returns the
- * per-launch durations in milliseconds (ms_out[esahrnet_launch_count]).  Synchronises `stream`. */
+ * per-launch durations in milliseconds (ms_out[esahrnet_launch_count]), with the duration of an
+ * empty event bracket on the same stream subtracted.  Synchronises `stream`. */
 int esahrnet_forward_timed(esahrnet_handle h, const void* x_dev, int n, int height, int width,
                            void* heat_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream,
                            float* ms_out);
