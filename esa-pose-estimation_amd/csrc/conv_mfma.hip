@@ -47,6 +47,9 @@
 #ifndef ESA_DO_STORE
 #define ESA_DO_STORE 1
 #endif
+#ifndef ESA_CONV_RING
+#define ESA_CONV_RING 1         // weight-thirds ring for 3x3 convs with >= 2 input chunks
+#endif
 
 namespace esa {
 
@@ -262,6 +265,206 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
 #undef ESA_DMA_W
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 convolution with >= 2 input-channel chunks: same tiling and MFMA loop, but the weight
+// fragments of chunk c+1 are DMA'd into LDS *while chunk c is being computed*.  The compute loop is
+// kx-major, so the weight image is kept as three 12-KB "thirds" (one per kx): as soon as every wave
+// has finished phase kx of chunk c (a barrier) slot kx is refilled with the kx-third of chunk c+1,
+// which is not read before phase kx of the next chunk.  No extra LDS, two more barriers per chunk,
+// and the L2 -> LDS weight latency (the exposed cost of the plain kernel on deep layers: 37 KB per
+// workgroup and chunk, re-fetched by every pixel tile) leaves the critical path.
+// LDS weight layout here: [kx][mt][ky][hi|lo][1 KB].
+template <int S, int TH, int MT>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_ring_kernel(ConvParams p, int tiles_x,
+                                                                    int tiles_y, int ctiles) {
+    using C = ConvCfg<3, S, TH, MT>;
+    constexpr int THIRD_FRAGS = MT * 3 * 2;                 // 1-KB fragments per kx-third
+    constexpr int THIRD_BYTES = THIRD_FRAGS * 1024;
+    constexpr int DPW = (THIRD_FRAGS + 3) / 4;              // DMA instructions per wave per third
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs = smem;
+    char* wsm = smem + C::XBYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunks = p.Cinp >> 5;
+    const int pix_stride = p.Cinp * 4;
+    int b = blockIdx.x;
+    const int ct = b % ctiles; b /= ctiles;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    int xg[C::XITER];
+    const int jst = tid & 7, q0 = tid >> 3;
+#pragma unroll
+    for (int it = 0; it < C::XITER; ++it) {
+        const int q = q0 + it * 32;
+        const int qy = q / C::IW, qx = q - qy * C::IW;
+        const int gy = oy0 * S - C::PAD + qy, gx = ox0 * S - C::PAD + qx;
+        const bool inside = q < C::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        xg[it] = inside ? ((gy * p.W + gx) * pix_stride + jst * 16) : -1;
+    }
+    char* xwr = xs + C::plane_off(jst) + q0 * 16;
+    const char* xn = p.x + (size_t)n * p.H * p.W * pix_stride;
+    const uint4* wbase = p.w + (size_t)(ct * MT) * nchunks * (C::TAPS * 128);
+    uint4 xr[C::XITER];
+#define RING_PREFETCH_X(CH)                                                                       \
+    {                                                                                             \
+        _Pragma("unroll") for (int it = 0; it < C::XITER; ++it) {                                 \
+            uint4 v = make_uint4(0, 0, 0, 0);                                                     \
+            if (xg[it] >= 0) v = *reinterpret_cast<const uint4*>(xn + xg[it] + (CH) * 128);       \
+            xr[it] = v;                                                                           \
+        }                                                                                         \
+    }
+    // third KX of chunk CH: fragment f = (mt, ky, part) -> LDS slot KX; one fragment per wave-instruction
+#define RING_DMA_W(CH, KX)                                                                        \
+    {                                                                                             \
+        _Pragma("unroll") for (int it = 0; it < DPW; ++it) {                                      \
+            const int f = it * 4 + wave;                                                          \
+            if (f < THIRD_FRAGS) {                                                                \
+                const int mt = f / 6, r6 = f - mt * 6, ky = r6 >> 1, part = r6 & 1;               \
+                const uint4* src = wbase + ((size_t)mt * nchunks + (CH)) * (C::TAPS * 128) +      \
+                                   ((ky * 3 + (KX)) * 2 + part) * 64 + lane;                      \
+                dma16(src, wsm + (KX) * THIRD_BYTES + __builtin_amdgcn_readfirstlane(f) * 1024);  \
+            }                                                                                     \
+        }                                                                                         \
+    }
+
+    const int g = lane >> 4;
+    const int ox = ox0 + (lane & 15);
+    const int opix = p.Coutp * 4;
+    f32x4 acc[MT][C::NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co = (ct * MT + m) * 16 + g * 4;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+        const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            acc[m][t] = bv;
+            const int oy = oy0 + wave * C::NT + t;
+            if (p.res && oy < p.OH && ox < p.OW) {
+                const size_t o = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + cofs;
+                const uint2 rh = *reinterpret_cast<const uint2*>(p.res + o);
+                const uint2 rl = *reinterpret_cast<const uint2*>(p.res + o + 16);
+                float r[4];
+                join4(rh, rl, r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[m][t][i] += r[i];
+            }
+        }
+    }
+    const char* xrd = xs + C::plane_off(2 * g) + ((wave * C::NT * S) * C::IW + (lane & 15) * S) * 16;
+    const char* wrd = wsm + lane * 16;
+    constexpr int ROWS = (C::NT - 1) * S + 3;
+
+    RING_DMA_W(0, 0)
+    RING_DMA_W(0, 1)
+    RING_DMA_W(0, 2)
+    RING_PREFETCH_X(0)
+    for (int c = 0; c < nchunks; ++c) {
+        if (c) __syncthreads();              // phase 2 of chunk c-1 done: X planes and slot 2 are free
+        // commit X(c); the wait hipcc puts in front of it (vmcnt(0): an LDS-DMA is pending) also
+        // retires the slot-0/slot-1 DMAs of this chunk, issued one and two MFMA phases ago
+#pragma unroll
+        for (int it = 0; it < C::XITER; ++it)
+            if (q0 + it * 32 < C::NPIX) *reinterpret_cast<uint4*>(xwr + it * 512) = xr[it];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                     // X(c), W(c,0), W(c,1) visible (c == 0: W(0,2) too)
+        if (c) RING_DMA_W(c, 2)              // lands during phases 0 and 1
+        if (c + 1 < nchunks) RING_PREFETCH_X(c + 1)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            bf16x8 wh[3][MT], wl[3][MT];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    wh[ky][m] = *reinterpret_cast<const bf16x8*>(wrd + kx * THIRD_BYTES + ((m * 3 + ky) * 2 + 0) * 1024);
+                    wl[ky][m] = *reinterpret_cast<const bf16x8*>(wrd + kx * THIRD_BYTES + ((m * 3 + ky) * 2 + 1) * 1024);
+                }
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                const int off = (i * C::IW + kx) * 16;
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xrd + off);
+                const bf16x8 xo = *reinterpret_cast<const bf16x8*>(xrd + off + C::LO_OFF);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int d = i - ky;
+                    if (d >= 0 && d % S == 0 && d / S < C::NT) {
+                        const int t = d / S;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ky][m], xh, acc[m][t], 0, 0, 0);
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky][m], xo, acc[m][t], 0, 0, 0);
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky][m], xh, acc[m][t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // slot kx is free once every wave is past phase kx: refill it for the next chunk.  The
+            // barrier after phase 1 also publishes slot 2 of THIS chunk (issued after the commit); its
+            // wait sits before the refill of slot 1 so that it never drains a just-issued DMA.
+            if (kx == 0 && c + 1 < nchunks) {
+                __syncthreads();
+                RING_DMA_W(c + 1, 0)
+            }
+            if (kx == 1) {
+                if (c) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (c || c + 1 < nchunks) __syncthreads();
+                if (c + 1 < nchunks) RING_DMA_W(c + 1, 1)
+            }
+        }
+    }
+#undef RING_PREFETCH_X
+#undef RING_DMA_W
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co = (ct * MT + m) * 16 + g * 4;
+        const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            const int oy = oy0 + wave * C::NT + t;
+            if (oy < p.OH && ox < p.OW) {
+                float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
+                if (p.relu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                if (p.out_f32) {
+                    const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
+                    *reinterpret_cast<f32x4*>(p.y + of) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    const size_t o = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + cofs;
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    *reinterpret_cast<uint2*>(p.y + o) = hi;
+                    *reinterpret_cast<uint2*>(p.y + o + 16) = lo;
+                }
+            }
+        }
+    }
+}
+
+template <int S, int TH, int MT>
+int launch_ring(const ConvParams& p, hipStream_t stream) {
+    using C = ConvCfg<3, S, TH, MT>;
+    static bool attr_set = false;
+    auto kern = conv_mfma_ring_kernel<S, TH, MT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
+    const int ctiles = p.Coutp / (16 * MT);
+    const long long nitems = (long long)p.N * tiles_y * tiles_x * ctiles;
+    if (nitems <= 0 || nitems > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nitems), dim3(NTHREADS), C::LDS_BYTES, stream, p, tiles_x, tiles_y, ctiles);
+    return (int)hipGetLastError();
+}
+
 int persistent_grid(long long nitems) {
     static int slots = 0;
     if (!slots) {
@@ -302,6 +505,11 @@ int launch_tp(const ConvParams& p, hipStream_t stream) {
 template <int KS, int S, int TH, int MT>
 int launch_t(const ConvParams& p, hipStream_t stream) {
     if (KS == 3 && S == 1 && p.Cinp == 32) return launch_tp<KS, S, TH, MT, true>(p, stream);
+#if ESA_CONV_RING
+    if constexpr (KS == 3) {
+        if (p.Cinp > 32) return launch_ring<S, TH, MT>(p, stream);
+    }
+#endif
     return launch_tp<KS, S, TH, MT, false>(p, stream);
 }
 
