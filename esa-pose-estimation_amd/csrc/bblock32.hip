@@ -23,6 +23,16 @@
 #include "kernels.h"
 #include "sb.h"
 
+#ifndef BB_DO_XLOAD
+#define BB_DO_XLOAD 1           // ablation switches for tuning experiments (all 1 in the shipped build)
+#endif
+#ifndef BB_DO_STORE
+#define BB_DO_STORE 1
+#endif
+#ifndef BB_DO_RES
+#define BB_DO_RES 1
+#endif
+
 namespace esa {
 namespace {
 
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void bblock32_kernel(BlockParams p, in
     {                                                                                            \
         _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                     \
             uint4 v = make_uint4(0, 0, 0, 0);                                                    \
-            if (xg[it] >= 0) v = *reinterpret_cast<const uint4*>(xn + xg[it]);                   \
+            if (BB_DO_XLOAD && xg[it] >= 0) v = *reinterpret_cast<const uint4*>(xn + xg[it]);    \
             xr[it] = v;                                                                          \
         }                                                                                        \
     }
@@ -144,8 +154,8 @@ __global__ __launch_bounds__(BTHREADS, 1) void bblock32_kernel(BlockParams p, in
                 const int oyc = min(oy0 + wave * 2 + t, p.H - 1), oxc = min(ox, p.W - 1);
                 const int co = m * 16 + g * 4;
                 const char* r = p.x + ((size_t)(n * p.H + oyc) * p.W + oxc) * 128 + (co >> 3) * 32 + ((co >> 2) & 1) * 8;
-                rh[m][t] = *reinterpret_cast<const uint2*>(r);
-                rl[m][t] = *reinterpret_cast<const uint2*>(r + 16);
+                rh[m][t] = BB_DO_RES ? *reinterpret_cast<const uint2*>(r) : make_uint2(0, 0);
+                rl[m][t] = BB_DO_RES ? *reinterpret_cast<const uint2*>(r + 16) : make_uint2(0, 0);
             }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void bblock32_kernel(BlockParams p, in
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int oy = oy0 + wave * 2 + t;
-                if (oy < p.H && ox < p.W) {
+                if ((BB_DO_STORE || acc2[m][t][0] == 123.456f) && oy < p.H && ox < p.W) {
                     const int co = m * 16 + g * 4;
                     char* o = p.y + ((size_t)(n * p.H + oy) * p.W + ox) * 128 + (co >> 3) * 32 + ((co >> 2) & 1) * 8;
                     float v[4];

@@ -519,7 +519,13 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
     if ((p.Cinp & 31) || (p.Coutp & 31)) return (int)hipErrorInvalidValue;
     // one image is addressed with 32-bit byte offsets inside the kernel
     if ((long long)p.H * p.W * p.Cinp * 4 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    if (k == 3 && stride == 1) return launch_t<3, 1, 16, 2>(p, stream);
+    if (k == 3 && stride == 1) {
+        // deep, small-resolution layers (e.g. 256 ch @ 16x16, batch 32) have too few 16x16 tiles to
+        // fill 2 workgroups on every CU: halve the tile height there
+        const long long items16 = (long long)p.N * ((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);
+        if (p.Cinp > 32 && items16 < 2LL * 256 * 3 / 4 && p.OH > 8) return launch_t<3, 1, 8, 2>(p, stream);
+        return launch_t<3, 1, 16, 2>(p, stream);
+    }
     if (k == 3 && stride == 2) return launch_t<3, 2, 4, 2>(p, stream);
     if (k == 1 && stride == 1) return launch_t<1, 1, 16, 2>(p, stream);
     return (int)hipErrorInvalidValue;
