@@ -86,6 +86,7 @@ struct Op {
     int terms[4] = {-1, -1, -1, -1};
     int nterms = 0;
     bool relu = false;
+    int lane = 0;               // execution lane (stream): 0 = caller's stream, 1..3 = side streams
 };
 
 struct ShapePlan {
@@ -113,6 +114,13 @@ struct esahrnet_ctx {
     bool committed = false;
     bool keep = false;
     bool fuse_big = true;       // fused stem + fused head (ESAHRNET_UNFUSED=1 selects the op-by-op plan)
+    // optional multi-stream execution of independent branches (ESAHRNET_STREAMS=4 enables)
+    int nlanes = 1;             // measured on MI355X (round 1): 4 lanes are SLOWER (4.42 vs 4.03 ms), see DESIGN.md
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> op_event;                 // one per op, created at commit
+    hipEvent_t entry_event = nullptr, lane_end[3] = {nullptr, nullptr, nullptr};
+    std::vector<std::vector<int>> waits;              // per op: ops on OTHER lanes it must wait for (per-shape plan)
+    std::vector<char> needs_event;                    // per op: someone on another lane waits for it
     ShapePlan sp;
     int max_level = 0;
 };
@@ -121,6 +129,7 @@ namespace {
 
 struct Builder {
     esahrnet_ctx& c;
+    int lane = 0;               // lane given to the ops being appended
     explicit Builder(esahrnet_ctx& ctx) : c(ctx) {}
 
     int spec(const std::string& name, const std::string& bn, int cin, int cout, int k, int stride,
@@ -152,7 +161,7 @@ struct Builder {
         d.cinp = pad32(d.c1 - d.c0); d.coutp = pad32(s.cout);
         c.dconvs.push_back(d);
         Op o;
-        o.kind = OP_CONV; o.dconv = (int)c.dconvs.size() - 1; o.in = in; o.res = res; o.relu = relu;
+        o.kind = OP_CONV; o.dconv = (int)c.dconvs.size() - 1; o.in = in; o.res = res; o.relu = relu; o.lane = lane;
         o.out = tensor(s.cout, s.level, tap);
         const int idx = (int)c.ops.size();
         c.tensors[o.out].def = idx;
@@ -162,7 +171,7 @@ struct Builder {
     }
     int fuse(const std::vector<int>& terms, int C, int level, bool relu, const std::string& tap = "") {
         Op o;
-        o.kind = OP_FUSE; o.nterms = (int)terms.size(); o.relu = relu;
+        o.kind = OP_FUSE; o.nterms = (int)terms.size(); o.relu = relu; o.lane = lane;
         o.out = tensor(C, level, tap);
         const int idx = (int)c.ops.size();
         c.tensors[o.out].def = idx;
@@ -177,7 +186,7 @@ struct Builder {
         const int c2 = spec(p + ".conv2", p + ".bn2", cout, cout, 3, 1, level, false, true);
         if (c.fuse_big && cin == cout && pad32(cin) == 32) {     // whole block in one kernel (bblock32.hip)
             Op o;
-            o.kind = OP_BLOCK; o.in = x; o.relu = true;
+            o.kind = OP_BLOCK; o.in = x; o.relu = true; o.lane = lane;
             for (int k = 0; k < 2; ++k) {
                 DevConv d;
                 d.spec = k ? c2 : c1; d.c0 = 0; d.c1 = cin; d.use_bias = true; d.cinp = 32; d.coutp = 32;
@@ -251,6 +260,7 @@ int build_plan(esahrnet_ctx& c) {
                 }
             } else {
                 int tt = ys.back();
+                B.lane = i;
                 const int nconv = i + 1 - (int)pre.size();
                 for (int j = 0; j < nconv; ++j) {
                     const std::string q = t + "." + std::to_string(i) + "." + std::to_string(j);
@@ -258,17 +268,21 @@ int build_plan(esahrnet_ctx& c) {
                     tt = B.conv(B.spec(q + ".0", q + ".1", pre.back(), co, 3, 2, (int)pre.size() + j + 1, false, true), tt, -1, true);
                 }
                 xs.push_back(tt);
+                B.lane = 0;
             }
         }
         // ---- HighResolutionModule x NUM_MODULES (:105-249) ----
         for (int m = 0; m < g.modules[s - 1]; ++m) {
             const std::string p = "stage" + std::to_string(s) + "." + std::to_string(m);
-            for (int b = 0; b < nb; ++b)
+            for (int b = 0; b < nb; ++b) {
+                B.lane = b;                  // the branches of a stage are independent chains
                 for (int k = 0; k < g.blocks[s - 1][b]; ++k)
                     xs[b] = B.basic_block(p + ".branches." + std::to_string(b) + "." + std::to_string(k),
                                           xs[b], cur[b], cur[b], 1 + b, "");
+            }
             std::vector<int> outs;
             for (int i = 0; i < nb; ++i) {
+                B.lane = i;                  // everything that feeds output branch i runs on lane i
                 std::vector<int> terms;
                 for (int j = 0; j < nb; ++j) {
                     const std::string q = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j);
@@ -291,6 +305,7 @@ int build_plan(esahrnet_ctx& c) {
                                       final_module ? "stage" + std::to_string(s) + "." + std::to_string(i) : ""));
             }
             xs = outs;
+            B.lane = 0;
         }
         ys = xs;
         pre = cur;
@@ -313,7 +328,9 @@ int build_plan(esahrnet_ctx& c) {
         for (int b = 1; b < 4; ++b) {
             const int save = c.specs[l0].level;
             c.specs[l0].level = 1 + b;
+            B.lane = b;
             o.terms[b - 1] = B.conv(l0, ys[b], -1, false, "", off, off + pre[b], false, true);
+            B.lane = 0;
             c.specs[l0].level = save;
             off += pre[b];
         }
@@ -401,17 +418,61 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
             free_list.pop_back();
         }
     };
+    // ---- dependencies for multi-stream execution: RAW (producer -> consumer) plus, because buffers are
+    // recycled, WAR/WAW (every earlier accessor of a region -> the op that overwrites it) ----------------
+    const size_t nops = c.ops.size();
+    auto inputs_of = [](const Op& o) {
+        std::vector<int> v;
+        if (o.in >= 0) v.push_back(o.in);
+        if (o.res >= 0) v.push_back(o.res);
+        for (int i = 0; i < o.nterms; ++i) if (o.terms[i] >= 0) v.push_back(o.terms[i]);
+        return v;
+    };
+    std::vector<std::vector<int>> accessors(c.tensors.size()), deps(nops);
+    for (size_t k = 0; k < nops; ++k) {
+        for (int t : inputs_of(c.ops[k])) { accessors[t].push_back((int)k); deps[k].push_back(c.tensors[t].def); }
+        if (c.ops[k].out >= 0) accessors[c.ops[k].out].push_back((int)k);
+    }
+    struct Retired { size_t off, len; int tensor; };
+    std::vector<Retired> retired;
     size_t high = 0;
-    for (size_t oi = 0; oi < c.ops.size(); ++oi) {
+    for (size_t oi = 0; oi < nops; ++oi) {
         const Op& o = c.ops[oi];
         if (o.out >= 0) {
-            c.tensors[o.out].off = alloc(bytes_of(c.tensors[o.out]));
-            high = std::max(high, std::max(top, c.tensors[o.out].off + bytes_of(c.tensors[o.out])));
+            const size_t len = bytes_of(c.tensors[o.out]);
+            const size_t off = alloc(len);
+            c.tensors[o.out].off = off;
+            for (const Retired& r : retired)
+                if (r.off < off + len && off < r.off + r.len)
+                    for (int a : accessors[r.tensor]) if (a < (int)oi) deps[oi].push_back(a);
+            high = std::max(high, std::max(top, off + len));
         }
         if (!c.keep)
-            for (Tensor& t : c.tensors)
-                if (t.def >= 0 && t.def <= (int)oi && t.last == (int)oi) release(t.off, bytes_of(t));
+            for (size_t ti = 0; ti < c.tensors.size(); ++ti) {
+                Tensor& t = c.tensors[ti];
+                if (t.def >= 0 && t.def <= (int)oi && t.last == (int)oi) {
+                    release(t.off, bytes_of(t));
+                    retired.push_back({t.off, bytes_of(t), (int)ti});
+                }
+            }
         high = std::max(high, top);
+    }
+    // per op: the cross-lane waits that are not already implied by in-order execution of each lane
+    c.waits.assign(nops, {});
+    c.needs_event.assign(nops, 0);
+    int last_waited[4][4];
+    for (auto& row : last_waited) for (int& v : row) v = -1;
+    for (size_t k = 0; k < nops; ++k) {
+        const int L = c.ops[k].lane;
+        int latest[4] = {-1, -1, -1, -1};
+        for (int d : deps[k])
+            if (d >= 0 && c.ops[d].lane != L) latest[c.ops[d].lane] = std::max(latest[c.ops[d].lane], d);
+        for (int l2 = 0; l2 < 4; ++l2)
+            if (latest[l2] > last_waited[L][l2]) {
+                c.waits[k].push_back(latest[l2]);
+                c.needs_event[latest[l2]] = 1;
+                last_waited[L][l2] = latest[l2];
+            }
     }
     sp.bytes = high;
     c.sp = sp;
@@ -428,6 +489,13 @@ void free_weights(esahrnet_ctx& c) {
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (void** p : {&c.head_w0, &c.head_w3})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
+    for (hipEvent_t& e : c.op_event) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    c.op_event.clear();
+    if (c.entry_event) { (void)hipEventDestroy(c.entry_event); c.entry_event = nullptr; }
+    for (int i = 0; i < 3; ++i) {
+        if (c.lane_end[i]) { (void)hipEventDestroy(c.lane_end[i]); c.lane_end[i] = nullptr; }
+        if (c.side[i]) { (void)hipStreamDestroy(c.side[i]); c.side[i] = nullptr; }
+    }
     c.committed = false;
 }
 
@@ -460,6 +528,7 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     c->cfg = *cfg;
     c->device = device;
     if (const char* e = getenv("ESAHRNET_UNFUSED")) c->fuse_big = !(e[0] && e[0] != '0');
+    if (const char* e = getenv("ESAHRNET_STREAMS")) c->nlanes = atoi(e) > 1 ? 4 : 1;
     if (build_plan(*c)) { delete c; return 1; }
     *out = c;
     return 0;
@@ -565,6 +634,15 @@ int esahrnet_commit(esahrnet_handle h) {
         std::copy(s3.b.begin(), s3.b.end(), b3.begin());
         if (upload(b0, reinterpret_cast<void**>(&h->head_b0)) || upload(b3, reinterpret_cast<void**>(&h->head_b3))) return 1;
     }
+    if (h->nlanes > 1) {     // side streams + events for the multi-stream executor
+        for (int i = 0; i < 3; ++i) {
+            HIP_OK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&h->lane_end[i], hipEventDisableTiming));
+        }
+        HIP_OK(hipEventCreateWithFlags(&h->entry_event, hipEventDisableTiming));
+        h->op_event.assign(h->ops.size(), nullptr);
+        for (hipEvent_t& e : h->op_event) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     h->committed = true;
     return 0;
 }
@@ -596,8 +674,29 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
     auto T = [&](int t) { return ws + h->tensors[t].off; };
     int op_index = 0;
     if (events && hipEventRecord(events[0], stream) != hipSuccess) return fail("forward: hipEventRecord failed");
+    // multi-stream executor: lane 0 is the caller's stream; independent branch chains run on side
+    // streams, ordered by per-op events (fork/join pattern, also valid under stream capture).  The timed
+    // and the keep-intermediates modes stay on one stream.
+    bool multi = !events && !h->keep && h->nlanes > 1 && h->side[0] != nullptr;
+    const hipStream_t caller = stream;
+    if (multi) {
+        // ROCm 7.0/7.2: pulling side streams into a stream capture crashes inside the runtime, so a
+        // forward that is being captured into a graph stays on the capturing stream
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) multi = false;
+    }
+    bool lane_used[4] = {true, false, false, false};
+    if (multi) HIP_OK(hipEventRecord(h->entry_event, caller));
     for (const Op& o : h->ops) {
         int rc = 0;
+        if (multi) {
+            stream = o.lane == 0 ? caller : h->side[o.lane - 1];
+            if (!lane_used[o.lane]) {
+                HIP_OK(hipStreamWaitEvent(stream, h->entry_event, 0));
+                lane_used[o.lane] = true;
+            }
+            for (int d : h->waits[op_index]) HIP_OK(hipStreamWaitEvent(stream, h->op_event[d], 0));
+        }
         switch (o.kind) {
             case OP_STEM: {
                 const Tensor& t = h->tensors[o.out];
@@ -691,9 +790,16 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
             }
         }
         if (rc) return fail("forward: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        if (multi && h->needs_event[op_index]) HIP_OK(hipEventRecord(h->op_event[op_index], stream));
         ++op_index;
         if (events && hipEventRecord(events[op_index], stream) != hipSuccess) return fail("forward: hipEventRecord failed");
     }
+    if (multi)               // join: the caller's stream continues only after every side lane has drained
+        for (int l = 1; l < 4; ++l)
+            if (lane_used[l]) {
+                HIP_OK(hipEventRecord(h->lane_end[l - 1], h->side[l - 1]));
+                HIP_OK(hipStreamWaitEvent(caller, h->lane_end[l - 1], 0));
+            }
     return 0;
 }
 

@@ -145,6 +145,22 @@ def test_unfused_plan_matches_reference_golden(env, golden_dir, tag, monkeypatch
     assert err <= GUARD, err
 
 
+def test_multistream_executor_matches_single_stream(env, monkeypatch):
+    """ESAHRNET_STREAMS=4 runs independent branch chains on side streams ordered by per-op events
+    (RAW + buffer-recycling WAR/WAW dependencies).  Must be bit-identical to the single-stream run."""
+    net1, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 5)
+    x = env["synth"].make_crops(8, 1, 128, 128, seed=5).cuda()
+    with torch.no_grad():
+        y1 = net1(x).clone()
+    monkeypatch.setenv("ESAHRNET_STREAMS", "4")
+    net4, _ = _build(env, "seg_hrnet2", (32, 64, 128, 256), 5)
+    with torch.no_grad():
+        ys = [net4(x).clone() for _ in range(5)]
+    torch.cuda.synchronize()
+    for y in ys:
+        assert torch.equal(y, y1)
+
+
 def test_intermediate_tensors_match_oracle(env):
     """Every named intermediate (stem, layer1, each stage's branches, head) vs the oracle."""
     net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 4)

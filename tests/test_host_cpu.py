@@ -120,7 +120,7 @@ def test_workspace_planning_and_shape_errors():
     nbytes = C.c_size_t()
     _lib.check(lib.esahrnet_workspace_bytes(h, 32, 256, 256, C.byref(nbytes)))
     per_crop = nbytes.value / 32
-    assert 20e6 < per_crop < 200e6          # recycled buffers: far below the ~340 MB sum of all activations
+    assert 5e6 < per_crop < 200e6          # recycled buffers: far below the ~340 MB sum of all activations
     _lib.check(lib.esahrnet_set_debug_keep(h, 1))
     keep = C.c_size_t()
     _lib.check(lib.esahrnet_workspace_bytes(h, 32, 256, 256, C.byref(keep)))
