@@ -5,6 +5,7 @@ Drop-in surface (mirrors the reference's flat modules):
     inference                heatmaps_to_keypoints, get_max_preds, get_final   (inference.py)
     config                   `config` CfgNode with the HRNet stage table        (config/default.py)
     parallel                 crop sharding + RCCL keypoint all-gather
+    pnp                      host pose solve after the path: EPnP + RANSAC, peak-weighted LM (pnp.py, cpnp)
     synth                    seed-reproducible weights / crops for tests and bench
 """
-__all__ = ["seg_hrnet", "seg_hrnet2", "inference", "config", "parallel", "synth", "hrnet", "build"]
+__all__ = ["seg_hrnet", "seg_hrnet2", "inference", "config", "parallel", "pnp", "synth", "hrnet", "build"]
