@@ -8,13 +8,17 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libesahrnet.so")
 MAX_BRANCHES = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Cfg(C.Structure):
     _fields_ = [("cin", C.c_int32), ("num_keypoints", C.c_int32), ("stem_width", C.c_int32),
                 ("widths", C.c_int32 * MAX_BRANCHES), ("blocks", (C.c_int32 * MAX_BRANCHES) * 4),
-                ("modules", C.c_int32 * 4), ("final_conv_kernel", C.c_int32)]
+                ("modules", C.c_int32 * 4), ("final_conv_kernel", C.c_int32), ("variant", C.c_int32)]
+
+
+class AuxDesc(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("shape", C.c_int32 * 4)]
 
 
 class ConvDesc(C.Structure):
@@ -42,6 +46,9 @@ _SIGS = {
     "esahrnet_conv_count": (C.c_int, [C.c_void_p]),
     "esahrnet_conv_desc_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ConvDesc)]),
     "esahrnet_set_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "esahrnet_aux_count": (C.c_int, [C.c_void_p]),
+    "esahrnet_aux_desc_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AuxDesc)]),
+    "esahrnet_set_aux": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "esahrnet_commit": (C.c_int, [C.c_void_p]),
     "esahrnet_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "esahrnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -1,0 +1,261 @@
+// cbam.hip — the CBAM attention of the seg_hrnet3 variant on SB tensors.
+//
+// Replaces ChannelAttention / SpatialAttention of models/seg_hrnet3.py:32-61 and their use inside
+// BasicBlock.forward (:90-91: out = ca(out)*out; out = sa(out)*out, before the residual add) and on
+// the stem skip (:516-517).  Four small memory-bound kernels, none of them on the matrix cores:
+//   pool_partial   per (n, c): sum and max over a slab of pixels            (AdaptiveAvg/MaxPool2d(1))
+//   ca_mlp         finishes the pooling, fc = 1x1 C->C/16, ReLU, 1x1 C/16->C on both, add, sigmoid
+//   cbam_maps      per pixel: mean_c and max_c of ca*x                      (torch.mean / torch.max, dim=1)
+//   cbam_apply     per pixel: sa = sigmoid(conv7x7([mean, max])), y = [relu](sa*ca*x [+ res]) -> SB slice
+// plus `resample_slice`: bilinear re-sampling (both align_corners conventions, or plain copy) of an
+// SB tensor into a channel slice of a wider SB tensor — the torch.cat([x0, up(x1), up(x2), up(x3)])
+// of :506-512 and the cat([up2(last_layer), cbam(x0)]) of :518, materialised because this variant's
+// last_layer[0] is a 3x3 convolution (no push-through-the-upsampling trick as in plan.hip).
+#include "kernels.h"
+#include "sb.h"
+
+namespace esa {
+namespace {
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ---- pool_partial: grid (P, N), 256 threads; thread = (pixel lane pl, channel group c8) ----------
+__global__ __launch_bounds__(256) void pool_partial_kernel(const char* x, float* partial, int HW, int Cp, int P) {
+    __shared__ float ssum[256 * 8];
+    __shared__ float smax[256 * 8];
+    const int G = Cp >> 3, PL = 256 / G;
+    const int slab = blockIdx.x, n = blockIdx.y;
+    const int S = (HW + P - 1) / P;
+    const int p0 = slab * S, p1 = min(HW, p0 + S);
+    const int tid = threadIdx.x, pl = tid / G, c8 = tid - pl * G;
+    float s[8], m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.f; m[i] = -INFINITY; }
+    if (pl < PL)
+        for (int p = p0 + pl; p < p1; p += PL) {
+            const char* a = x + ((size_t)n * HW + p) * (size_t)(Cp * 4) + c8 * 32;
+            float v[8];
+            join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s[i] += v[i]; m[i] = fmaxf(m[i], v[i]); }
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ssum[tid * 8 + i] = s[i]; smax[tid * 8 + i] = m[i]; }
+    __syncthreads();
+    if (tid < Cp) {                       // channel c = tid: reduce over the pixel lanes
+        const int g = tid >> 3, i = tid & 7;
+        float a = 0.f, b = -INFINITY;
+        for (int l = 0; l < PL; ++l) { a += ssum[(l * G + g) * 8 + i]; b = fmaxf(b, smax[(l * G + g) * 8 + i]); }
+        float* o = partial + (((size_t)n * P + slab) * Cp + tid) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
+// ---- ca_mlp: grid N, 256 threads ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ca_mlp_kernel(const float* partial, const float* w0, const float* w2,
+                                                     float* ca, int HW, int C, int Cp, int Cr, int P) {
+    __shared__ float avg[512], mx[512], ha[64], hm[64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < Cp; c += 256) {
+        float a = 0.f, b = -INFINITY;
+        for (int s = 0; s < P; ++s) {
+            const float* q = partial + (((size_t)n * P + s) * Cp + c) * 2;
+            a += q[0]; b = fmaxf(b, q[1]);
+        }
+        avg[c] = a / (float)HW; mx[c] = b;
+    }
+    __syncthreads();
+    if (tid < Cr) {                       // fc[0] (no bias) + ReLU, on both pooled vectors
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < C; ++c) { a += w0[tid * C + c] * avg[c]; b += w0[tid * C + c] * mx[c]; }
+        ha[tid] = fmaxf(a, 0.f); hm[tid] = fmaxf(b, 0.f);
+    }
+    __syncthreads();
+    for (int c = tid; c < Cp; c += 256) {
+        float v = 0.f;
+        if (c < C) {
+            float a = 0.f, b = 0.f;
+            for (int j = 0; j < Cr; ++j) { a += w2[c * Cr + j] * ha[j]; b += w2[c * Cr + j] * hm[j]; }
+            v = sigmoidf(a + b);
+        }
+        ca[(size_t)n * Cp + c] = v;
+    }
+}
+
+// ---- cbam_maps: one thread per pixel --------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cbam_maps_kernel(const char* x, const float* ca, float* maps, long long total,
+                                                        int HW, int C, int Cp) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int n = (int)(idx / HW);
+    const float* cn = ca + (size_t)n * Cp;
+    const char* a = x + (size_t)idx * (size_t)(Cp * 4);
+    float s = 0.f, m = -INFINITY;
+    for (int c8 = 0; c8 * 8 < C; ++c8) {
+        float v[8];
+        join8(*reinterpret_cast<const uint4*>(a + c8 * 32), *reinterpret_cast<const uint4*>(a + c8 * 32 + 16), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (c8 * 8 + i < C) { const float u = v[i] * cn[c8 * 8 + i]; s += u; m = fmaxf(m, u); }
+    }
+    maps[idx * 2 + 0] = s / (float)C;
+    maps[idx * 2 + 1] = m;
+}
+
+// ---- cbam_apply: one thread per pixel ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cbam_apply_kernel(CbamApplyParams p, long long total) {
+    __shared__ float w[98];
+    if (threadIdx.x < 98) w[threadIdx.x] = p.w_sa[threadIdx.x];
+    __syncthreads();
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int HW = p.H * p.W;
+    const int n = (int)(idx / HW);
+    const int pix = (int)(idx - (long long)n * HW);
+    const int y = pix / p.W, x = pix - y * p.W;
+    float acc = 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+        const int yy = y + ky - 3;
+        if (yy < 0 || yy >= p.H) continue;
+        for (int kx = 0; kx < 7; ++kx) {
+            const int xx = x + kx - 3;
+            if (xx < 0 || xx >= p.W) continue;
+            const float* mp = p.maps + (((size_t)n * p.H + yy) * p.W + xx) * 2;
+            acc += w[ky * 7 + kx] * mp[0] + w[49 + ky * 7 + kx] * mp[1];
+        }
+    }
+    const float sa = sigmoidf(acc);
+    const float* cn = p.ca + (size_t)n * p.Cp;
+    const char* a = p.x + (size_t)idx * (size_t)(p.Cp * 4);
+    const char* r = p.res ? p.res + (size_t)idx * (size_t)(p.Cp * 4) : nullptr;
+    char* o = p.y + (size_t)idx * (size_t)p.y_pix_bytes + (p.y_c0 >> 3) * 32;
+    for (int c8 = 0; c8 < (p.Cp >> 3); ++c8) {
+        float v[8];
+        join8(*reinterpret_cast<const uint4*>(a + c8 * 32), *reinterpret_cast<const uint4*>(a + c8 * 32 + 16), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (sa * cn[c8 * 8 + i]) * v[i];      // (ca*x) then sa*(.): same association
+        if (r) {
+            float rv[8];
+            join8(*reinterpret_cast<const uint4*>(r + c8 * 32), *reinterpret_cast<const uint4*>(r + c8 * 32 + 16), rv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += rv[i];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        *reinterpret_cast<uint4*>(o + c8 * 32) = hi;
+        *reinterpret_cast<uint4*>(o + c8 * 32 + 16) = lo;
+    }
+}
+
+// ---- resample_slice: thread = (dst pixel, 8-channel group of the source) ---------------------------------
+struct LerpR { int i0, i1; float l0, l1; };
+__device__ __forceinline__ LerpR lerp_any(int dst, int in, int out, int align) {
+    float src;
+    if (align) {
+        const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+        src = scale * (float)dst;
+    } else {
+        const float scale = (float)in / (float)out;
+        src = scale * ((float)dst + 0.5f) - 0.5f;
+        src = src < 0.f ? 0.f : src;
+    }
+    LerpR r;
+    r.i0 = min((int)src, in - 1);
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void resample_slice_kernel(ResampleParams p, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int G = (p.C + 7) >> 3;             // only the groups that hold real channels
+    const int c8 = (int)(idx % G);
+    long long pix = idx / G;
+    const int x = (int)(pix % p.W);
+    long long row = pix / p.W;
+    const int y = (int)(row % p.H);
+    const int n = (int)(row / p.H);
+    float v[8];
+    auto ld = [&](size_t sp, float* out) {
+        const char* a = p.x + sp * (size_t)(p.Cp_src * 4) + c8 * 32;
+        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), out);
+    };
+    if (p.h == p.H && p.w == p.W) {
+        ld((size_t)pix, v);
+    } else {
+        const LerpR ly = lerp_any(y, p.h, p.H, p.align), lx = lerp_any(x, p.w, p.W, p.align);
+        const size_t r0 = ((size_t)n * p.h + ly.i0) * p.w, r1 = ((size_t)n * p.h + ly.i1) * p.w;
+        float v00[8], v01[8], v10[8], v11[8];
+        ld(r0 + lx.i0, v00); ld(r0 + lx.i1, v01); ld(r1 + lx.i0, v10); ld(r1 + lx.i1, v11);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[i] = ly.l0 * (lx.l0 * v00[i] + lx.l1 * v01[i]) + ly.l1 * (lx.l0 * v10[i] + lx.l1 * v11[i]);
+    }
+    uint4 hi, lo;
+    split8(v, hi, lo);
+    char* o = p.y + (size_t)pix * (size_t)p.y_pix_bytes + ((p.y_c0 >> 3) + c8) * 32;
+    *reinterpret_cast<uint4*>(o) = hi;
+    *reinterpret_cast<uint4*>(o + 16) = lo;
+}
+
+__global__ __launch_bounds__(256) void zero_slice_kernel(char* y, long long npix, int y_pix_bytes, int c0, int ngroups) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npix * ngroups) return;
+    const long long pix = idx / ngroups;
+    const int g = (int)(idx - pix * ngroups);
+    char* o = y + (size_t)pix * (size_t)y_pix_bytes + ((c0 >> 3) + g) * 32;
+    *reinterpret_cast<uint4*>(o) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(o + 16) = make_uint4(0, 0, 0, 0);
+}
+
+inline int blocks(long long total) { return (int)((total + 255) / 256); }
+
+}  // namespace
+
+int launch_pool_partial(const char* x, float* partial, int N, int HW, int Cp, int P, hipStream_t s) {
+    if ((Cp & 7) || Cp > 256 || Cp < 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pool_partial_kernel, dim3(P, N), dim3(256), 0, s, x, partial, HW, Cp, P);
+    return (int)hipGetLastError();
+}
+
+int launch_ca_mlp(const float* partial, const float* w0, const float* w2, float* ca, int N, int HW, int C, int Cp,
+                  int Cr, int P, hipStream_t s) {
+    if (Cp > 512 || Cr > 64 || Cr < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ca_mlp_kernel, dim3(N), dim3(256), 0, s, partial, w0, w2, ca, HW, C, Cp, Cr, P);
+    return (int)hipGetLastError();
+}
+
+int launch_cbam_maps(const char* x, const float* ca, float* maps, int N, int HW, int C, int Cp, hipStream_t s) {
+    const long long total = (long long)N * HW;
+    hipLaunchKernelGGL(cbam_maps_kernel, dim3(blocks(total)), dim3(256), 0, s, x, ca, maps, total, HW, C, Cp);
+    return (int)hipGetLastError();
+}
+
+int launch_cbam_apply(const CbamApplyParams& p, hipStream_t s) {
+    const long long total = (long long)p.N * p.H * p.W;
+    if ((p.y_c0 & 7) || (p.Cp & 7)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cbam_apply_kernel, dim3(blocks(total)), dim3(256), 0, s, p, total);
+    return (int)hipGetLastError();
+}
+
+int launch_resample_slice(const ResampleParams& p, hipStream_t s) {
+    if ((p.y_c0 & 7) || (p.Cp_src & 7)) return (int)hipErrorInvalidValue;
+    const long long total = (long long)p.N * p.H * p.W * ((p.C + 7) >> 3);
+    hipLaunchKernelGGL(resample_slice_kernel, dim3(blocks(total)), dim3(256), 0, s, p, total);
+    return (int)hipGetLastError();
+}
+
+int launch_zero_slice(char* y, long long npix, int y_pix_bytes, int c0, int nchan, hipStream_t s) {
+    if ((c0 & 7) || (nchan & 7) || nchan <= 0) return (int)hipErrorInvalidValue;
+    const long long total = npix * (nchan >> 3);
+    hipLaunchKernelGGL(zero_slice_kernel, dim3(blocks(total)), dim3(256), 0, s, y, npix, y_pix_bytes, c0, nchan >> 3);
+    return (int)hipGetLastError();
+}
+
+}  // namespace esa

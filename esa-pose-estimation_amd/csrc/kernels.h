@@ -31,6 +31,7 @@ struct StemParams {
     const float* w;     // f32 [cout/8][cin][9][8]  (repacked: 8 consecutive couts innermost)
     const float* bias;  // f32 [cout]
     int N, H, W, cin, cout;
+    int relu;           // 0: raw conv output (seg_hrnet3 keeps the pre-BN conv1 tensor for its skip)
 };
 int launch_stem(const StemParams& p, hipStream_t stream);
 
@@ -98,6 +99,30 @@ int launch_head(const HeadParams& p, hipStream_t stream);
 bool head_fused_supported(int H, int W, const int th[3], const int tw[3], int C0p, int K);
 size_t head_w3_bytes(int K, int Ctp);
 void pack_head_w3(const float* w, int K, int Ct, int Ctp, void* dst);
+
+// ---- CBAM attention of the seg_hrnet3 variant + slice re-sampling (cbam.hip) --------------------
+int launch_pool_partial(const char* x, float* partial, int N, int HW, int Cp, int P, hipStream_t s);
+int launch_ca_mlp(const float* partial, const float* w0, const float* w2, float* ca, int N, int HW, int C,
+                  int Cp, int Cr, int P, hipStream_t s);
+int launch_cbam_maps(const char* x, const float* ca, float* maps, int N, int HW, int C, int Cp, hipStream_t s);
+struct CbamApplyParams {
+    const char* x;      // SB [N][H][W][Cp]
+    const char* res;    // SB same shape or nullptr
+    const float* ca;    // f32 [N][Cp]   channel attention
+    const float* maps;  // f32 [N][H][W][2]  (mean_c, max_c) of ca*x
+    const float* w_sa;  // f32 [2][7][7]
+    char* y;            // SB, pixel pitch y_pix_bytes, written at channel offset y_c0 (multiple of 8)
+    int N, H, W, Cp, y_pix_bytes, y_c0, relu;
+};
+int launch_cbam_apply(const CbamApplyParams& p, hipStream_t s);
+struct ResampleParams {
+    const char* x;      // SB [N][h][w][Cp_src]
+    char* y;            // SB [N][H][W][..], pixel pitch y_pix_bytes, channel offset y_c0 (multiple of 8)
+    int N, h, w, H, W, C, Cp_src, y_pix_bytes, y_c0;
+    int align;          // 1: align_corners=True, 0: False (irrelevant when h==H && w==W: copy)
+};
+int launch_resample_slice(const ResampleParams& p, hipStream_t s);
+int launch_zero_slice(char* y, long long npix, int y_pix_bytes, int c0, int nchan, hipStream_t s);
 
 // ---- arg-max + log-quadratic refine (keypoints.hip) ----------------------------------------
 int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, hipStream_t stream);

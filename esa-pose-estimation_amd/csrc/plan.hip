@@ -64,15 +64,27 @@ struct DevConv {                // one MFMA convolution launch (a ConvSpec or a 
     int c0, c1;                 // input-channel slice of the spec
     bool use_bias;
     bool out_f32 = false;       // output plain f32 NHWC instead of SB (head terms)
+    std::vector<int> perm;      // optional input-channel permutation: packed ci -> spec ci
     int cinp, coutp;
     void* w = nullptr;          // device, packed
     float* bias = nullptr;      // device, f32 [coutp]
 };
 
-enum OpKind { OP_STEM, OP_STEMF, OP_CONV, OP_BLOCK, OP_FUSE, OP_HEAD, OP_FINAL };
+enum OpKind { OP_STEM, OP_STEMF, OP_CONV, OP_BLOCK, OP_FUSE, OP_HEAD, OP_FINAL,
+              // seg_hrnet3 (CBAM) variant only:
+              OP_STEMRAW, OP_POOL, OP_MLP, OP_MAPS, OP_APPLY, OP_RESAMPLE, OP_ZERO, OP_TONCHW };
+
+struct AuxSpec {                // a non-conv parameter tensor (CBAM weights)
+    std::string name;
+    int shape[4];
+    std::vector<float> data;
+    bool set = false;
+    float* dev = nullptr;
+};
 
 struct Tensor {
     int C, Cp, level;
+    int flat = 0;               // > 0: plain f32 scratch of `flat` floats per sample (no spatial extent)
     std::string tap;            // name for esahrnet_tap_read, "" if anonymous
     int def = -1, last = -1;    // op indices
     size_t off = 0;             // per-shape plan
@@ -87,6 +99,10 @@ struct Op {
     int nterms = 0;
     bool relu = false;
     int lane = 0;               // execution lane (stream): 0 = caller's stream, 1..3 = side streams
+    int aux[3] = {-1, -1, -1};  // CBAM ops: fc.0, fc.2, sa.conv1
+    int c0 = 0;                 // channel offset inside `out` (OP_APPLY / OP_RESAMPLE / OP_ZERO)
+    int nchan = 0;              // OP_ZERO: channels to clear;  OP_RESAMPLE/OP_APPLY/OP_MAPS: real channels
+    int align = 0;              // OP_RESAMPLE: align_corners
 };
 
 struct ShapePlan {
@@ -104,6 +120,8 @@ struct esahrnet_ctx {
     std::vector<ConvSpec> specs;
     std::map<std::string, int> spec_by_name;
     std::vector<DevConv> dconvs;
+    std::vector<AuxSpec> aux;
+    float *stemraw_w = nullptr, *stemraw_b = nullptr;     // variant 1: un-normalised conv1 for the skip
     std::vector<Tensor> tensors;
     std::vector<Op> ops;
     int spec_stem = -1, spec_final = -1;
@@ -179,8 +197,64 @@ struct Builder {
         c.ops.push_back(o);
         return o.out;
     }
+    int aux(const std::string& name, int a, int b, int kh, int kw) {
+        AuxSpec s;
+        s.name = name; s.shape[0] = a; s.shape[1] = b; s.shape[2] = kh; s.shape[3] = kw;
+        c.aux.push_back(s);
+        return (int)c.aux.size() - 1;
+    }
+    int push(Op& o) {
+        o.lane = lane;
+        const int idx = (int)c.ops.size();
+        if (o.out >= 0 && c.tensors[o.out].def < 0) c.tensors[o.out].def = idx;
+        use(o.in, idx); use(o.res, idx);
+        for (int i = 0; i < 4; ++i) use(o.terms[i], idx);
+        c.ops.push_back(o);
+        return idx;
+    }
+    int flat_tensor(int floats_per_sample) {
+        Tensor t;
+        t.C = t.Cp = 0; t.level = 0; t.flat = floats_per_sample;
+        c.tensors.push_back(t);
+        return (int)c.tensors.size() - 1;
+    }
+    // CBAM (seg_hrnet3.py:32-61, 90-91): y[:, c0:c0+C] = [relu]( sa(ca*x) * (ca*x) [+ res] ); prefix p
+    // names the owner of .ca / .sa ("" = the network's own).  Returns nothing: writes into `y`.
+    static constexpr int POOL_SLABS = 64;
+    void cbam(const std::string& p, int x, int C, int res, bool relu, int y, int y_c0) {
+        const std::string q = p.empty() ? "" : p + ".";
+        const int cr = C / 16;
+        const int a0 = aux(q + "ca.fc.0.weight", cr, C, 1, 1), a1 = aux(q + "ca.fc.2.weight", C, cr, 1, 1);
+        const int a2 = aux(q + "sa.conv1.weight", 1, 2, 7, 7);
+        const int level = c.tensors[x].level, Cp = c.tensors[x].Cp;
+        const int partial = flat_tensor(POOL_SLABS * Cp * 2), cav = flat_tensor(Cp);
+        Tensor mt; mt.C = 2; mt.Cp = 2; mt.level = level;
+        c.tensors.push_back(mt);
+        const int maps = (int)c.tensors.size() - 1;
+        { Op o; o.kind = OP_POOL; o.in = x; o.out = partial; push(o); }
+        { Op o; o.kind = OP_MLP; o.in = partial; o.out = cav; o.aux[0] = a0; o.aux[1] = a1; o.nchan = C; o.terms[0] = x; push(o); }
+        { Op o; o.kind = OP_MAPS; o.in = x; o.terms[1] = cav; o.out = maps; o.nchan = C; push(o); }
+        { Op o; o.kind = OP_APPLY; o.in = x; o.res = res; o.terms[1] = cav; o.terms[2] = maps; o.aux[2] = a2;
+          o.out = y; o.c0 = y_c0; o.relu = relu; o.nchan = C; push(o); }
+    }
+    // BasicBlock of seg_hrnet3.py:64-103: conv-bn-relu-conv-bn, CBAM, (+res), relu
+    int basic_block_cbam(const std::string& p, int x, int cin, int cout, int level, const std::string& tap) {
+        int res = x;
+        const int c1 = spec(p + ".conv1", p + ".bn1", cin, cout, 3, 1, level, false, true);
+        const int c2 = spec(p + ".conv2", p + ".bn2", cout, cout, 3, 1, level, false, false);
+        if (cin != cout) {
+            const int d = spec(p + ".downsample.0", p + ".downsample.1", cin, cout, 1, 1, level, false, false);
+            res = conv(d, x, -1, false);
+        }
+        const int o1 = conv(c1, x, -1, true);
+        const int o2 = conv(c2, o1, -1, false);
+        const int y = tensor(cout, level, tap);
+        cbam(p, o2, cout, res, true, y, 0);
+        return y;
+    }
     // BasicBlock (seg_hrnet.py:32-61): conv-bn-relu-conv-bn (+res) relu
     int basic_block(const std::string& p, int x, int cin, int cout, int level, const std::string& tap) {
+        if (c.cfg.variant == 1) return basic_block_cbam(p, x, cin, cout, level, tap);
         int res = x;
         const int c1 = spec(p + ".conv1", p + ".bn1", cin, cout, 3, 1, level, false, true);
         const int c2 = spec(p + ".conv2", p + ".bn2", cout, cout, 3, 1, level, false, true);
@@ -217,7 +291,14 @@ int build_plan(esahrnet_ctx& c) {
     c.spec_stem = B.spec("conv1", "bn1", g.cin, sw, 3, 1, 0, false, true);
     const int spec_conv2 = B.spec("conv2", "bn2", sw, sw, 3, 2, 1, false, true);
     int x;
-    if (c.fuse_big) {       // conv1 recomputed per tile inside the conv2 kernel (stem_fused.hip)
+    int stem_raw = -1;
+    if (g.variant == 1) {   // seg_hrnet3.py:473-475: x0 = conv1(x0) is kept (pre-BN) for the CBAM skip
+        c.fuse_big = false;
+        { Op o; o.kind = OP_STEMRAW; o.out = B.tensor(sw, 0, "stem_raw"); stem_raw = o.out;
+          o.aux[0] = B.aux("conv1.weight", sw, g.cin, 3, 3); B.push(o); }
+        { Op o; o.kind = OP_STEM; o.out = B.tensor(sw, 0, "stem1"); B.push(o); }
+        x = B.conv(spec_conv2, c.ops.back().out, -1, true, "stem2");
+    } else if (c.fuse_big) {       // conv1 recomputed per tile inside the conv2 kernel (stem_fused.hip)
         DevConv d;
         d.spec = spec_conv2; d.c0 = 0; d.c1 = sw; d.use_bias = true;
         d.cinp = pad32(sw); d.coutp = pad32(sw);
@@ -314,6 +395,41 @@ int build_plan(esahrnet_ctx& c) {
     int tot = 0;
     for (int v : pre) tot += v;
     const int K = g.num_keypoints;
+    if (g.variant == 1) {
+        // seg_hrnet3.py:363-383, 506-520: cat of the up-sampled branches (materialised: last_layer[0] is a
+        // 3x3 conv here), 3x3 480->480, 1x1 480->K, up x2 (align_corners=True), cat with CBAM(stem skip),
+        // 3x3 (K+64)->K.  The second concat is laid out [skip | heat-maps] so that both slices start on
+        // an 8-channel group; output_layer's input channels are permuted accordingly when packed.
+        const int l0 = B.spec("last_layer.0", "last_layer.1", tot, tot, 3, 1, 1, true, true);
+        const int l3 = B.spec("last_layer.3", "last_layer.4", tot, K, 1, 1, 1, true, true);
+        c.spec_final = B.spec("output_layer.0", "", K + sw, K, 3, 1, 0, true, false);
+        const int cat = B.tensor(tot, 1, "head_cat");
+        int off = 0;
+        for (size_t b = 0; b < ys.size(); ++b) {
+            Op o; o.kind = OP_RESAMPLE; o.in = ys[b]; o.out = cat; o.c0 = off; o.nchan = pre[b]; o.align = 0;
+            B.push(o);
+            off += pre[b];
+        }
+        if (pad32(tot) > ((tot + 7) & ~7)) {
+            Op o; o.kind = OP_ZERO; o.out = cat; o.terms[0] = cat; o.c0 = (tot + 7) & ~7; o.nchan = pad32(tot) - ((tot + 7) & ~7);
+            B.push(o);
+        }
+        const int h0 = B.conv(l0, cat, -1, true, "head0");
+        const int h3 = B.conv(l3, h0, -1, true, "head3");
+        const int cat2 = B.tensor(sw + K, 0, "head_cat2");
+        B.cbam("", stem_raw, sw, -1, false, cat2, 0);
+        { Op o; o.kind = OP_RESAMPLE; o.in = h3; o.out = cat2; o.terms[0] = cat2; o.c0 = sw; o.nchan = K; o.align = 1; B.push(o); }
+        if (pad32(sw + K) > sw + ((K + 7) & ~7)) {
+            Op o; o.kind = OP_ZERO; o.out = cat2; o.terms[0] = cat2; o.c0 = sw + ((K + 7) & ~7); o.nchan = pad32(sw + K) - o.c0;
+            B.push(o);
+        }
+        const int oc = B.conv(c.spec_final, cat2, -1, false, "out_sb");
+        std::vector<int>& perm = c.dconvs[c.ops.back().dconv].perm;     // packed ci -> reference ci
+        for (int i = 0; i < sw; ++i) perm.push_back(K + i);              // skip channels come second in the reference
+        for (int i = 0; i < K; ++i) perm.push_back(i);
+        { Op o; o.kind = OP_TONCHW; o.in = oc; B.push(o); }
+        return 0;
+    }
     const int l0 = B.spec("last_layer.0", "last_layer.1", tot, tot, 1, 1, 1, true, true);
     const int l3 = B.spec("last_layer.3", "last_layer.4", tot, K, 1, 1, 1, true, true);
     c.spec_final = B.spec("output_layer.0", "", K + g.cin, K, 3, 1, 0, true, false);
@@ -390,7 +506,7 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
     std::vector<Free> free_list;
     size_t top = 0;
     auto bytes_of = [&](const Tensor& t) {
-        size_t b = (size_t)n * sp.lh[t.level] * sp.lw[t.level] * t.Cp * 4;
+        size_t b = t.flat ? (size_t)n * t.flat * 4 : (size_t)n * sp.lh[t.level] * sp.lw[t.level] * t.Cp * 4;
         return (b + 255) & ~(size_t)255;
     };
     auto alloc = [&](size_t len) {
@@ -429,16 +545,20 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
         return v;
     };
     std::vector<std::vector<int>> accessors(c.tensors.size()), deps(nops);
+    std::vector<std::vector<int>> writers(c.tensors.size());
     for (size_t k = 0; k < nops; ++k) {
-        for (int t : inputs_of(c.ops[k])) { accessors[t].push_back((int)k); deps[k].push_back(c.tensors[t].def); }
-        if (c.ops[k].out >= 0) accessors[c.ops[k].out].push_back((int)k);
+        for (int t : inputs_of(c.ops[k])) {
+            accessors[t].push_back((int)k);
+            for (int wr : writers[t]) deps[k].push_back(wr);         // every earlier writer (slices!)
+        }
+        if (c.ops[k].out >= 0) { accessors[c.ops[k].out].push_back((int)k); writers[c.ops[k].out].push_back((int)k); }
     }
     struct Retired { size_t off, len; int tensor; };
     std::vector<Retired> retired;
     size_t high = 0;
     for (size_t oi = 0; oi < nops; ++oi) {
         const Op& o = c.ops[oi];
-        if (o.out >= 0) {
+        if (o.out >= 0 && c.tensors[o.out].def == (int)oi) {     // (slice writers re-use the allocation)
             const size_t len = bytes_of(c.tensors[o.out]);
             const size_t off = alloc(len);
             c.tensors[o.out].off = off;
@@ -489,6 +609,8 @@ void free_weights(esahrnet_ctx& c) {
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (void** p : {&c.head_w0, &c.head_w3})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
+    for (AuxSpec& a : c.aux) if (a.dev) { (void)hipFree(a.dev); a.dev = nullptr; }
+    for (float** p : {&c.stemraw_w, &c.stemraw_b}) if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (hipEvent_t& e : c.op_event) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     c.op_event.clear();
     if (c.entry_event) { (void)hipEventDestroy(c.entry_event); c.entry_event = nullptr; }
@@ -520,6 +642,13 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     if (cfg->cin < 1 || cfg->cin > 4) return fail("cin=%d unsupported (1..4)", cfg->cin);
     if (cfg->num_keypoints < 1 || esa::final_kt(cfg->num_keypoints) < 0) return fail("num_keypoints=%d unsupported (1..32)", cfg->num_keypoints);
     if (cfg->stem_width < 1 || cfg->blocks[0][0] < 1) return fail("bad stem_width/blocks");
+    if (cfg->variant != 0 && cfg->variant != 1) return fail("variant=%d unsupported (0: seg_hrnet/2, 1: seg_hrnet3)", cfg->variant);
+    if (cfg->variant == 1) {
+        if (cfg->stem_width % 16) return fail("variant 1: stem_width must be a multiple of 16 (ChannelAttention ratio)");
+        for (int b = 0; b < ESAHRNET_MAX_BRANCHES; ++b)
+            if (cfg->blocks[3][b] > 0 && (cfg->widths[b] < 16 || cfg->widths[b] % 8))
+                return fail("variant 1: branch widths must be >= 16 and multiples of 8 (got %d)", cfg->widths[b]);
+    }
     for (int s = 1; s < 4; ++s)
         if (cfg->modules[s] < 1) return fail("NUM_MODULES of stage %d must be >= 1", s + 1);
     for (int b = 0; b < ESAHRNET_MAX_BRANCHES; ++b)
@@ -567,10 +696,32 @@ int esahrnet_set_conv(esahrnet_handle h, int i, const float* w, const float* b) 
     return 0;
 }
 
+int esahrnet_aux_count(esahrnet_handle h) { return h ? (int)h->aux.size() : -1; }
+
+int esahrnet_aux_desc_get(esahrnet_handle h, int i, esahrnet_aux_desc* out) {
+    if (!h || !out || i < 0 || i >= (int)h->aux.size()) return fail("aux_desc_get: bad index %d", i);
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", h->aux[i].name.c_str());
+    for (int k = 0; k < 4; ++k) out->shape[k] = h->aux[i].shape[k];
+    return 0;
+}
+
+int esahrnet_set_aux(esahrnet_handle h, int i, const float* w) {
+    if (!h || !w || i < 0 || i >= (int)h->aux.size()) return fail("set_aux: bad argument (index %d)", i);
+    AuxSpec& a = h->aux[i];
+    const size_t n = (size_t)a.shape[0] * a.shape[1] * a.shape[2] * a.shape[3];
+    a.data.assign(w, w + n);
+    for (float v : a.data) if (!std::isfinite(v)) return fail("set_aux(%s): non-finite value", a.name.c_str());
+    a.set = true;
+    return 0;
+}
+
 int esahrnet_commit(esahrnet_handle h) {
     if (!h) return fail("commit: null handle");
     for (const ConvSpec& s : h->specs)
         if (!s.set) return fail("commit: weights of '%s' were never set", s.name.c_str());
+    for (const AuxSpec& a : h->aux)
+        if (!a.set) return fail("commit: tensor '%s' was never set", a.name.c_str());
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail("commit: no HIP device visible — the MI355X kernels cannot run (no CPU fallback exists)");
@@ -583,8 +734,10 @@ int esahrnet_commit(esahrnet_handle h) {
         std::vector<float> w((size_t)s.cout * cin * taps);
         for (int co = 0; co < s.cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
-                for (int t = 0; t < taps; ++t)
-                    w[((size_t)co * cin + ci) * taps + t] = s.w[((size_t)co * s.cin + d.c0 + ci) * taps + t];
+                for (int t = 0; t < taps; ++t) {
+                    const int src_ci = d.perm.empty() ? d.c0 + ci : d.perm[ci];
+                    w[((size_t)co * cin + ci) * taps + t] = s.w[((size_t)co * s.cin + src_ci) * taps + t];
+                }
         packed.assign(esa::packed_weight_bytes(d.coutp, d.cinp, s.k), 0);
         esa::pack_conv_weights(w.data(), s.cout, cin, s.k, d.coutp, d.cinp, packed.data());
         if (upload(packed, &d.w)) return 1;
@@ -604,7 +757,7 @@ int esahrnet_commit(esahrnet_handle h) {
         }
         if (upload(w, reinterpret_cast<void**>(&h->stem_w)) || upload(b, reinterpret_cast<void**>(&h->stem_b))) return 1;
     }
-    {   // final: [K+cin][9][KT]
+    if (h->cfg.variant == 0) {   // final: [K+cin][9][KT]
         const ConvSpec& s = h->specs[h->spec_final];
         const int kt = esa::final_kt(s.cout);
         std::vector<float> w((size_t)s.cin * 9 * kt, 0.f), b(kt, 0.f);
@@ -616,6 +769,19 @@ int esahrnet_commit(esahrnet_handle h) {
         }
         if (upload(w, reinterpret_cast<void**>(&h->final_w)) || upload(b, reinterpret_cast<void**>(&h->final_b))) return 1;
     }
+    for (AuxSpec& a : h->aux)
+        if (upload(a.data, reinterpret_cast<void**>(&a.dev))) return 1;
+    for (const Op& o : h->ops)
+        if (o.kind == OP_STEMRAW) {   // un-normalised conv1 in the stem kernel's [cout/8][cin][9][8] layout, zero bias
+            const AuxSpec& a = h->aux[o.aux[0]];
+            const int cout = a.shape[0], cin = a.shape[1], coutp = pad32(cout);
+            std::vector<float> w((size_t)coutp * cin * 9, 0.f), b(coutp, 0.f);
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        w[(((size_t)(co >> 3) * cin + ci) * 9 + t) * 8 + (co & 7)] = a.data[((size_t)co * cin + ci) * 9 + t];
+            if (upload(w, reinterpret_cast<void**>(&h->stemraw_w)) || upload(b, reinterpret_cast<void**>(&h->stemraw_b))) return 1;
+        }
     if (h->spec_l0 >= 0) {   // fused head: W0 slice (standard pack), W3 (permuted-K pack), biases
         const ConvSpec& s0 = h->specs[h->spec_l0];
         const ConvSpec& s3 = h->specs[h->spec_l3];
@@ -701,8 +867,71 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
             case OP_STEM: {
                 const Tensor& t = h->tensors[o.out];
                 esa::StemParams p{static_cast<const float*>(x_dev), T(o.out), h->stem_w, h->stem_b,
-                                  n, height, width, h->cfg.cin, t.Cp};
+                                  n, height, width, h->cfg.cin, t.Cp, 1};
                 rc = esa::launch_stem(p, stream);
+                break;
+            }
+            case OP_STEMRAW: {
+                const Tensor& t = h->tensors[o.out];
+                esa::StemParams p{static_cast<const float*>(x_dev), T(o.out), h->stemraw_w, h->stemraw_b,
+                                  n, height, width, h->cfg.cin, t.Cp, 0};
+                rc = esa::launch_stem(p, stream);
+                break;
+            }
+            case OP_POOL: {
+                const Tensor& ti = h->tensors[o.in];
+                const int HW = sp.lh[ti.level] * sp.lw[ti.level];
+                rc = esa::launch_pool_partial(T(o.in), reinterpret_cast<float*>(T(o.out)), n, HW, ti.Cp,
+                                              std::min(Builder::POOL_SLABS, HW), stream);
+                break;
+            }
+            case OP_MLP: {
+                const Tensor& tx = h->tensors[o.terms[0]];
+                const int HW = sp.lh[tx.level] * sp.lw[tx.level];
+                rc = esa::launch_ca_mlp(reinterpret_cast<const float*>(T(o.in)), h->aux[o.aux[0]].dev, h->aux[o.aux[1]].dev,
+                                        reinterpret_cast<float*>(T(o.out)), n, HW, o.nchan, tx.Cp, o.nchan / 16,
+                                        std::min(Builder::POOL_SLABS, HW), stream);
+                break;
+            }
+            case OP_MAPS: {
+                const Tensor& ti = h->tensors[o.in];
+                rc = esa::launch_cbam_maps(T(o.in), reinterpret_cast<const float*>(T(o.terms[1])),
+                                           reinterpret_cast<float*>(T(o.out)), n, sp.lh[ti.level] * sp.lw[ti.level],
+                                           o.nchan, ti.Cp, stream);
+                break;
+            }
+            case OP_APPLY: {
+                const Tensor& ti = h->tensors[o.in];
+                const Tensor& to = h->tensors[o.out];
+                esa::CbamApplyParams p{};
+                p.x = T(o.in); p.res = o.res >= 0 ? T(o.res) : nullptr;
+                p.ca = reinterpret_cast<const float*>(T(o.terms[1])); p.maps = reinterpret_cast<const float*>(T(o.terms[2]));
+                p.w_sa = h->aux[o.aux[2]].dev; p.y = T(o.out);
+                p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level]; p.Cp = ti.Cp;
+                p.y_pix_bytes = to.Cp * 4; p.y_c0 = o.c0; p.relu = o.relu;
+                rc = esa::launch_cbam_apply(p, stream);
+                break;
+            }
+            case OP_RESAMPLE: {
+                const Tensor& ti = h->tensors[o.in];
+                const Tensor& to = h->tensors[o.out];
+                esa::ResampleParams p{};
+                p.x = T(o.in); p.y = T(o.out); p.N = n;
+                p.h = sp.lh[ti.level]; p.w = sp.lw[ti.level]; p.H = sp.lh[to.level]; p.W = sp.lw[to.level];
+                p.C = o.nchan; p.Cp_src = ti.Cp; p.y_pix_bytes = to.Cp * 4; p.y_c0 = o.c0; p.align = o.align;
+                rc = esa::launch_resample_slice(p, stream);
+                break;
+            }
+            case OP_ZERO: {
+                const Tensor& to = h->tensors[o.out];
+                rc = esa::launch_zero_slice(T(o.out), (long long)n * sp.lh[to.level] * sp.lw[to.level], to.Cp * 4,
+                                            o.c0, o.nchan, stream);
+                break;
+            }
+            case OP_TONCHW: {
+                const Tensor& ti = h->tensors[o.in];
+                rc = esa::launch_sb_to_nchw(T(o.in), n, h->cfg.num_keypoints, height, width, ti.Cp,
+                                            static_cast<float*>(heat_dev), stream);
                 break;
             }
             case OP_STEMF: {
@@ -845,7 +1074,10 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
     level_dims(*h, height, width, lh, lw);
     memset(out, 0, sizeof *out);
     const Op& o = h->ops[index];
-    auto tbytes = [&](int t) { const Tensor& x = h->tensors[t]; return (double)n * lh[x.level] * lw[x.level] * x.Cp * 4.0; };
+    auto tbytes = [&](int t) {
+        const Tensor& x = h->tensors[t];
+        return x.flat ? (double)n * x.flat * 4.0 : (double)n * lh[x.level] * lw[x.level] * x.Cp * 4.0;
+    };
     switch (o.kind) {
         case OP_STEM: {
             const ConvSpec& s = h->specs[h->spec_stem];
@@ -905,6 +1137,15 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             snprintf(out->label, sizeof out->label, "fuse -> %s", h->tensors[o.out].tap.c_str());
             out->bytes = tbytes(o.out);
             for (int i = 0; i < o.nterms; ++i) out->bytes += tbytes(o.terms[i]);
+            break;
+        }
+        case OP_STEMRAW: case OP_POOL: case OP_MLP: case OP_MAPS: case OP_APPLY: case OP_RESAMPLE: case OP_ZERO:
+        case OP_TONCHW: {
+            static const char* names[] = {"stem_kernel(raw)", "pool_partial", "ca_mlp", "cbam_maps", "cbam_apply",
+                                          "resample_slice", "zero_slice", "sb_to_nchw"};
+            snprintf(out->kernel, sizeof out->kernel, "%s", names[o.kind - OP_STEMRAW]);
+            snprintf(out->label, sizeof out->label, "seg_hrnet3");
+            out->bytes = (o.in >= 0 ? tbytes(o.in) : 0.0) + (o.out >= 0 ? tbytes(o.out) : 0.0);
             break;
         }
         case OP_FINAL: {

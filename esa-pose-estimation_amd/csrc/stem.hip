@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, long long total
             }
         }
     }
+    if (p.relu) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = fmaxf(acc[i], 0.f);
+        for (int i = 0; i < 8; ++i) acc[i] = fmaxf(acc[i], 0.f);
+    }
     uint4 hi, lo;
     split8(acc, hi, lo);
     char* o = p.y + (((size_t)(n * p.H + y) * p.W + x) * p.cout) * 4 + c8 * 32;

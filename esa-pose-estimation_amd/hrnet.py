@@ -31,11 +31,11 @@ logger = logging.getLogger(__name__)
 BN_MOMENTUM = 0.01           # models/seg_hrnet.py:23 (irrelevant at inference, kept for parity)
 
 
-def _cfg_struct(config, cin: int, num_keypoints: int) -> _lib.Cfg:
+def _cfg_struct(config, cin: int, num_keypoints: int, variant: int = 0) -> _lib.Cfg:
     extra = config.MODEL.EXTRA.HIGH_RESOLUTION_NET if hasattr(config, "MODEL") else \
         config["MODEL"]["EXTRA"]["HIGH_RESOLUTION_NET"]
     s = _lib.Cfg()
-    s.cin, s.num_keypoints, s.stem_width = cin, num_keypoints, 64
+    s.cin, s.num_keypoints, s.stem_width, s.variant = cin, num_keypoints, 64, variant
     fk = extra["FINAL_CONV_KERNEL"] if "FINAL_CONV_KERNEL" in extra else 1
     s.final_conv_kernel = int(fk)
     for i in range(4):
@@ -82,13 +82,14 @@ def _place(root: nn.Module, dotted: str, leaf: nn.Module):
 class HighResolutionNet(nn.Module):
     CIN = 3                  # models/seg_hrnet.py:265
     NUM_KEYPOINTS = 32       # models/seg_hrnet.py:324
+    VARIANT = 0              # 1 = seg_hrnet3.py (CBAM)
 
     def __init__(self, config, **kwargs):
         super().__init__()
         cin = int(kwargs.pop("cin", self.CIN))
         k = int(kwargs.pop("num_keypoints", self.NUM_KEYPOINTS))
         self._cin, self._k = cin, k
-        self._cfg_struct = _cfg_struct(config, cin, k)
+        self._cfg_struct = _cfg_struct(config, cin, k, int(kwargs.pop("variant", self.VARIANT)))
         object.__setattr__(self, "_rt", _Runtime(self._cfg_struct))
         self._descs = self._rt.conv_descs()
         for d in self._descs:
@@ -96,6 +97,15 @@ class HighResolutionNet(nn.Module):
             _place(self, d["name"], conv)
             if d["bn"]:
                 _place(self, d["bn"], nn.BatchNorm2d(d["cout"], momentum=BN_MOMENTUM))
+        # parameters that are not convolutions of the main graph (seg_hrnet3: ChannelAttention.fc,
+        # SpatialAttention.conv1); some names alias a conv that already exists (conv1.weight)
+        self._aux = self._rt.aux_descs()
+        have = set(dict(self.named_parameters()).keys())
+        for a in self._aux:
+            if a["name"] in have:
+                continue
+            co, ci, kh, kw = a["shape"]
+            _place(self, a["name"][: -len(".weight")], nn.Conv2d(ci, co, (kh, kw), padding=(kh // 2, kw // 2), bias=False))
         self.eval()
 
     # ---- reference API -------------------------------------------------------------------------
@@ -170,6 +180,14 @@ class _Runtime:
         except Exception:
             pass
 
+    def aux_descs(self):
+        out = []
+        for i in range(self.lib.esahrnet_aux_count(self._probe)):
+            d = _lib.AuxDesc()
+            _lib.check(self.lib.esahrnet_aux_desc_get(self._probe, i, C.byref(d)))
+            out.append(dict(name=d.name.decode(), shape=tuple(d.shape)))
+        return out
+
     def conv_descs(self):
         out = []
         for i in range(self.lib.esahrnet_conv_count(self._probe)):
@@ -202,6 +220,9 @@ class _Runtime:
         for i, d in enumerate(module._descs):
             w, b = fold_conv(sd, d["name"], d["bn"], d["has_bias"])
             _lib.check(self.lib.esahrnet_set_conv(h, i, w.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+        for i, a in enumerate(module._aux):
+            w = np.ascontiguousarray(sd[a["name"]].detach().cpu().float().numpy())
+            _lib.check(self.lib.esahrnet_set_aux(h, i, w.ctypes.data_as(C.c_void_p)))
         with torch.cuda.device(device):
             _lib.check(self.lib.esahrnet_commit(h))
         self.handles[device.index] = (h, key)

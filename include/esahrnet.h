@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define ESAHRNET_MAX_BRANCHES 4
-#define ESAHRNET_ABI_VERSION 1
+#define ESAHRNET_ABI_VERSION 2
 
 typedef struct esahrnet_ctx* esahrnet_handle;
 typedef void* esahrnet_stream; /* hipStream_t */
@@ -48,7 +48,16 @@ typedef struct esahrnet_cfg {
     int32_t blocks[4][ESAHRNET_MAX_BRANCHES];       /* NUM_BLOCKS per stage (stage1 uses [0][0]) */
     int32_t modules[4];          /* NUM_MODULES per stage (stage1 entry unused)                */
     int32_t final_conv_kernel;   /* FINAL_CONV_KERNEL, must be 1 (config/default.py:43)        */
+    int32_t variant;             /* 0: seg_hrnet.py / seg_hrnet2.py;  1: seg_hrnet3.py (CBAM in every
+                                    BasicBlock and on the 64-ch pre-BN stem skip, 3x3 last_layer[0],
+                                    output_layer over [heatmaps, skip]; models/seg_hrnet3.py)         */
 } esahrnet_cfg;
+
+/* A parameter tensor that is not a convolution of the main graph (variant 1: the CBAM weights). */
+typedef struct esahrnet_aux_desc {
+    char name[96];               /* state_dict key, e.g. "layer1.0.ca.fc.0.weight"               */
+    int32_t shape[4];            /* Conv2d weight shape [out][in][kh][kw]                          */
+} esahrnet_aux_desc;
 
 /* One Conv2d of the reference module tree, by its state_dict prefix. */
 typedef struct esahrnet_conv_desc {
@@ -73,6 +82,10 @@ int esahrnet_conv_desc_get(esahrnet_handle h, int index, esahrnet_conv_desc* out
 /* Hand over one convolution with BatchNorm ALREADY FOLDED (eval mode, eps 1e-5):
  * w: host f32 [cout][cin][k][k], b: host f32 [cout] (never NULL). */
 int esahrnet_set_conv(esahrnet_handle h, int index, const float* w, const float* b);
+int esahrnet_aux_count(esahrnet_handle h);
+int esahrnet_aux_desc_get(esahrnet_handle h, int index, esahrnet_aux_desc* out);
+/* w: host f32, prod(shape) elements, exactly the state_dict tensor (no folding applies). */
+int esahrnet_set_aux(esahrnet_handle h, int index, const float* w);
 /* Pack (split-bf16, MFMA fragment order) and upload every convolution.  Synchronous. */
 int esahrnet_commit(esahrnet_handle h);
 

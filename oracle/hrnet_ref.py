@@ -32,14 +32,15 @@ BN_EPS = 1e-5  # nn.BatchNorm2d default, seg_hrnet.py:22
 
 def default_cfg(cin: int = 1, num_keypoints: int = 11, widths=(32, 64, 128, 256),
                 blocks=((2,), (2, 2), (2, 2, 2), (4, 4, 4, 4)), modules=(1, 1, 1, 1),
-                stem_width: int = 64, final_conv_kernel: int = 1) -> dict:
+                stem_width: int = 64, final_conv_kernel: int = 1, variant: int = 0) -> dict:
     """Stage table of config/default.py:39-74 as a plain dict.
 
-    cin=1,K=11 is seg_hrnet2.py:265,324;  cin=3,K=32 is seg_hrnet.py:265,324.
+    cin=1,K=11 is seg_hrnet2.py:265,324;  cin=3,K=32 is seg_hrnet.py:265,324;
+    variant=1, cin=1, K=30 is seg_hrnet3.py (CBAM, 3x3 last_layer[0], 64-channel stem skip).
     """
     return dict(cin=cin, num_keypoints=num_keypoints, widths=tuple(widths),
                 blocks=tuple(tuple(b) for b in blocks), modules=tuple(modules),
-                stem_width=stem_width, final_conv_kernel=final_conv_kernel)
+                stem_width=stem_width, final_conv_kernel=final_conv_kernel, variant=variant)
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -59,11 +60,28 @@ def _bn(sd, name, x):
                         training=False, eps=BN_EPS)
 
 
+def _cbam(sd, p, x):
+    """seg_hrnet3.py:32-61: out = ca(x) * x; out = sa(out) * out.  ``p`` = owner prefix ('' = the net)."""
+    q = p + "." if p else ""
+    w0, w2 = sd[q + "ca.fc.0.weight"].to(x.dtype), sd[q + "ca.fc.2.weight"].to(x.dtype)
+
+    def fc(v):
+        return F.conv2d(F.relu(F.conv2d(v, w0)), w2)
+    ca = torch.sigmoid(fc(F.adaptive_avg_pool2d(x, 1)) + fc(F.adaptive_max_pool2d(x, 1)))
+    x = ca * x
+    m = torch.cat([torch.mean(x, dim=1, keepdim=True), torch.max(x, dim=1, keepdim=True)[0]], dim=1)
+    sa = torch.sigmoid(F.conv2d(m, sd[q + "sa.conv1.weight"].to(x.dtype), padding=3))
+    return sa * x
+
+
 def _basic_block(sd, p, x):
-    """seg_hrnet.py:45-61. ``p`` is the block prefix, e.g. 'layer1.0'."""
+    """seg_hrnet.py:45-61 (seg_hrnet3.py:82-103 when the block owns CBAM weights).
+    ``p`` is the block prefix, e.g. 'layer1.0'."""
     res = x
     out = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x)))
     out = _bn(sd, p + ".bn2", _conv(sd, p + ".conv2", out))
+    if (p + ".ca.fc.0.weight") in sd:                # seg_hrnet3.py:90-91
+        out = _cbam(sd, p, out)
     if (p + ".downsample.0.weight") in sd:           # seg_hrnet.py:55-56
         res = _bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x))
     return F.relu(out + res)
@@ -132,7 +150,10 @@ def forward(sd: dict, cfg: dict, x0: torch.Tensor, taps: dict | None = None) -> 
             taps[name] = t
         return t
 
-    x = F.relu(_bn(sd, "bn1", _conv(sd, "conv1", x0)))                 # :426-428
+    v3 = cfg.get("variant", 0) == 1
+    skip = _conv(sd, "conv1", x0)                                      # seg_hrnet3.py:473: pre-BN, kept
+    tap("stem_raw", skip)
+    x = F.relu(_bn(sd, "bn1", skip))                                   # :426-428
     tap("stem1", x)
     x = F.relu(_bn(sd, "bn2", _conv(sd, "conv2", x, stride=2)))        # :429-431
     tap("stem2", x)
@@ -158,6 +179,8 @@ def forward(sd: dict, cfg: dict, x0: torch.Tensor, taps: dict | None = None) -> 
     tap("head3", h)
     # nn.UpsamplingBilinear2d(scale_factor=2) == align_corners=True (:330)
     h = F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=True)
+    if v3:                                                                       # seg_hrnet3.py:516-518
+        return _conv(sd, "output_layer.0", torch.cat([h, _cbam(sd, "", skip)], 1))
     return _conv(sd, "output_layer.0", torch.cat([h, x0], 1))                   # :332-340, :469
 
 
@@ -231,7 +254,8 @@ def enumerate_convs(cfg: dict) -> list:
     tot = sum(pre)
     K = cfg["num_keypoints"]
     fk = cfg["final_conv_kernel"]
-    add("last_layer.0", tot, tot, 1, 1, 2, bias=True, bn="last_layer.1", relu=True)
+    v3 = cfg.get("variant", 0) == 1
+    add("last_layer.0", tot, tot, 3 if v3 else 1, 1, 2, bias=True, bn="last_layer.1", relu=True)
     add("last_layer.3", tot, K, fk, 1, 2, bias=True, bn="last_layer.4", relu=True)
-    add("output_layer.0", K + cfg["cin"], K, 3, 1, 1, bias=True)
+    add("output_layer.0", K + (sw if v3 else cfg["cin"]), K, 3, 1, 1, bias=True)
     return out

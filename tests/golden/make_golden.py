@@ -29,7 +29,7 @@ warnings.filterwarnings("ignore")
 import torch  # noqa: E402
 
 import esa_pose_estimation_amd.synth as synth  # noqa: E402
-from models import seg_hrnet, seg_hrnet2  # noqa: E402  (reference)
+from models import seg_hrnet, seg_hrnet2, seg_hrnet3  # noqa: E402  (reference)
 import inference as ref_inference  # noqa: E402  (reference)
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -53,7 +53,7 @@ DEFAULT_BLOCKS = ((2,), (2, 2), (2, 2, 2), (4, 4, 4, 4))
 
 
 def build_ref(variant, widths, blocks, seed):
-    mod = {"seg_hrnet": seg_hrnet, "seg_hrnet2": seg_hrnet2}[variant]
+    mod = {"seg_hrnet": seg_hrnet, "seg_hrnet2": seg_hrnet2, "seg_hrnet3": seg_hrnet3}[variant]
     net = mod.get_seg_model(ref_cfg(widths, blocks)).eval()
     sd = synth.make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=seed)
     net.load_state_dict(sd, strict=True)
@@ -157,6 +157,9 @@ def main():
     full_net("w32_hrnet2_128", "seg_hrnet2", w32, DEFAULT_BLOCKS, 1, 128, seed=3)
     full_net("w32_hrnet2_256", "seg_hrnet2", w32, DEFAULT_BLOCKS, 1, 256, seed=0)
     full_net("w32_hrnet_256", "seg_hrnet", w32, DEFAULT_BLOCKS, 1, 256, seed=0, subsample=4)
+    # seg_hrnet3 (CBAM; ChannelAttention needs C // 16 >= 1, so the small case uses widths 16..128)
+    full_net("small_hrnet3_64", "seg_hrnet3", (16, 32, 64, 128), DEFAULT_BLOCKS, 2, 64, seed=4)
+    full_net("w32_hrnet3_128", "seg_hrnet3", w32, DEFAULT_BLOCKS, 1, 128, seed=5)
     hr_module("hrmodule2", 2, (16, 32), (2, 2), 32, seed=11)
     hr_module("hrmodule3", 3, (16, 32, 64), (1, 2, 1), 32, seed=12)
     hr_module("hrmodule4", 4, (8, 16, 32, 64), (1, 1, 1, 2), 32, seed=13)

@@ -23,11 +23,11 @@ GUARD = 2e-4        # regression guard for the split-bf16 kernels
 def env():
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a GPU (torch.cuda.is_available() is False)")
-    from esa_pose_estimation_amd import _lib, config, inference, seg_hrnet, seg_hrnet2, synth
+    from esa_pose_estimation_amd import _lib, config, inference, seg_hrnet, seg_hrnet2, seg_hrnet3, synth
     from oracle import hrnet_ref, keypoints_ref
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     return dict(lib=_lib.lib(), L=_lib, config=config, inference=inference, seg_hrnet=seg_hrnet,
-                seg_hrnet2=seg_hrnet2, synth=synth, hrnet_ref=hrnet_ref, kref=keypoints_ref)
+                seg_hrnet2=seg_hrnet2, seg_hrnet3=seg_hrnet3, synth=synth, hrnet_ref=hrnet_ref, kref=keypoints_ref)
 
 
 def _stream():
@@ -104,7 +104,8 @@ def _build(env, variant, widths, seed):
     return net.cuda().eval(), sd
 
 
-GOLDEN = ["tiny_hrnet2_64", "tiny_hrnet_64", "w32_hrnet2_128", "w32_hrnet2_256", "w32_hrnet_256"]
+GOLDEN = ["tiny_hrnet2_64", "tiny_hrnet_64", "w32_hrnet2_128", "w32_hrnet2_256", "w32_hrnet_256",
+          "small_hrnet3_64", "w32_hrnet3_128"]       # the last two: seg_hrnet3 (CBAM), SURVEY.md §8a row a18
 
 
 @pytest.mark.parametrize("tag", GOLDEN)
@@ -359,3 +360,20 @@ def test_w48_384_matches_oracle(env):
     err = (y - ref).abs().max().item()
     print(f"W48 384x384: Linf vs CPU oracle {err:.3e}")
     assert err <= GUARD, err
+
+
+def test_hrnet3_intermediates_match_oracle(env):
+    """seg_hrnet3 (CBAM): every named intermediate incl. the pre-BN stem skip vs the oracle."""
+    net, sd = _build(env, "seg_hrnet3", (32, 64, 128, 256), 9)
+    x = env["synth"].make_crops(2, 1, 64, 96, seed=9)
+    cfg = env["hrnet_ref"].default_cfg(1, 30, variant=1)
+    taps_ref = {}
+    with torch.no_grad():
+        out_ref = env["hrnet_ref"].forward(sd, cfg, x, taps_ref)
+        taps = net.taps(x.cuda())
+    assert {"stem_raw", "stem1", "layer1", "stage4.3", "head0", "head3"} <= set(taps)
+    for name, ref in taps_ref.items():
+        if name in taps:
+            err = (taps[name].cpu() - ref).abs().max().item()
+            assert err <= GUARD, (name, err)
+    assert (taps["heatmaps"].cpu() - out_ref).abs().max().item() <= GUARD
