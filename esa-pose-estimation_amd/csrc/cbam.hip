@@ -82,73 +82,92 @@ __global__ __launch_bounds__(256) void ca_mlp_kernel(const float* partial, const
     }
 }
 
-// ---- cbam_maps: one thread per pixel --------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cbam_maps_kernel(const char* x, const float* ca, float* maps, long long total,
+// ---- cbam_maps: thread = (pixel, 8-channel group), group fastest -> coalesced 32-B pieces; the G
+// partial (sum, max) of a pixel meet in LDS ------------------------------------------------------------
+__global__ __launch_bounds__(256) void cbam_maps_kernel(const char* x, const float* ca, float* maps, long long npix,
                                                         int HW, int C, int Cp) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int n = (int)(idx / HW);
-    const float* cn = ca + (size_t)n * Cp;
-    const char* a = x + (size_t)idx * (size_t)(Cp * 4);
+    __shared__ float ps[256], pm[256];
+    const int G = Cp >> 3, PPB = 256 / G;                 // pixels per block
+    const int tid = threadIdx.x, pl = tid / G, c8 = tid - pl * G;
+    const long long pix = (long long)blockIdx.x * PPB + pl;
     float s = 0.f, m = -INFINITY;
-    for (int c8 = 0; c8 * 8 < C; ++c8) {
+    if (pl < PPB && pix < npix && c8 * 8 < C) {
+        const int n = (int)(pix / HW);
+        const float* cn = ca + (size_t)n * Cp + c8 * 8;
+        const char* a = x + (size_t)pix * (size_t)(Cp * 4) + c8 * 32;
         float v[8];
-        join8(*reinterpret_cast<const uint4*>(a + c8 * 32), *reinterpret_cast<const uint4*>(a + c8 * 32 + 16), v);
+        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (c8 * 8 + i < C) { const float u = v[i] * cn[c8 * 8 + i]; s += u; m = fmaxf(m, u); }
+            if (c8 * 8 + i < C) { const float u = v[i] * cn[i]; s += u; m = fmaxf(m, u); }
     }
-    maps[idx * 2 + 0] = s / (float)C;
-    maps[idx * 2 + 1] = m;
+    ps[tid] = s; pm[tid] = m;
+    __syncthreads();
+    if (pl < PPB && pix < npix && c8 == 0) {
+        float a = 0.f, b = -INFINITY;
+        for (int g = 0; g < G; ++g) { a += ps[pl * G + g]; b = fmaxf(b, pm[pl * G + g]); }
+        maps[pix * 2 + 0] = a / (float)C;
+        maps[pix * 2 + 1] = b;
+    }
 }
 
-// ---- cbam_apply: one thread per pixel ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cbam_apply_kernel(CbamApplyParams p, long long total) {
+// ---- cbam_apply: thread = (pixel, 8-channel group); the pixel's first thread evaluates the 7x7
+// spatial attention once and shares it through LDS ----------------------------------------------------
+__global__ __launch_bounds__(256) void cbam_apply_kernel(CbamApplyParams p, long long npix) {
     __shared__ float w[98];
+    __shared__ float sas[256];
     if (threadIdx.x < 98) w[threadIdx.x] = p.w_sa[threadIdx.x];
     __syncthreads();
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    const int G = p.Cp >> 3, PPB = 256 / G;
+    const int tid = threadIdx.x, pl = tid / G, c8 = tid - pl * G;
+    const long long idx = (long long)blockIdx.x * PPB + pl;
+    const bool live = pl < PPB && idx < npix;
     const int HW = p.H * p.W;
-    const int n = (int)(idx / HW);
-    const int pix = (int)(idx - (long long)n * HW);
-    const int y = pix / p.W, x = pix - y * p.W;
-    float acc = 0.f;
-    for (int ky = 0; ky < 7; ++ky) {
-        const int yy = y + ky - 3;
-        if (yy < 0 || yy >= p.H) continue;
-        for (int kx = 0; kx < 7; ++kx) {
-            const int xx = x + kx - 3;
-            if (xx < 0 || xx >= p.W) continue;
-            const float* mp = p.maps + (((size_t)n * p.H + yy) * p.W + xx) * 2;
-            acc += w[ky * 7 + kx] * mp[0] + w[49 + ky * 7 + kx] * mp[1];
+    int n = 0;
+    if (live) {
+        n = (int)(idx / HW);
+        if (c8 == 0) {
+            const int pix = (int)(idx - (long long)n * HW);
+            const int y = pix / p.W, x = pix - y * p.W;
+            float acc = 0.f;
+            for (int ky = 0; ky < 7; ++ky) {
+                const int yy = y + ky - 3;
+                if (yy < 0 || yy >= p.H) continue;
+                for (int kx = 0; kx < 7; ++kx) {
+                    const int xx = x + kx - 3;
+                    if (xx < 0 || xx >= p.W) continue;
+                    const float* mp = p.maps + (((size_t)n * p.H + yy) * p.W + xx) * 2;
+                    acc += w[ky * 7 + kx] * mp[0] + w[49 + ky * 7 + kx] * mp[1];
+                }
+            }
+            sas[pl] = sigmoidf(acc);
         }
     }
-    const float sa = sigmoidf(acc);
-    const float* cn = p.ca + (size_t)n * p.Cp;
-    const char* a = p.x + (size_t)idx * (size_t)(p.Cp * 4);
-    const char* r = p.res ? p.res + (size_t)idx * (size_t)(p.Cp * 4) : nullptr;
-    char* o = p.y + (size_t)idx * (size_t)p.y_pix_bytes + (p.y_c0 >> 3) * 32;
-    for (int c8 = 0; c8 < (p.Cp >> 3); ++c8) {
-        float v[8];
-        join8(*reinterpret_cast<const uint4*>(a + c8 * 32), *reinterpret_cast<const uint4*>(a + c8 * 32 + 16), v);
+    __syncthreads();
+    if (!live) return;
+    const float sa = sas[pl];
+    const float* cn = p.ca + (size_t)n * p.Cp + c8 * 8;
+    const char* a = p.x + (size_t)idx * (size_t)(p.Cp * 4) + c8 * 32;
+    float v[8];
+    join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (sa * cn[c8 * 8 + i]) * v[i];      // (ca*x) then sa*(.): same association
-        if (r) {
-            float rv[8];
-            join8(*reinterpret_cast<const uint4*>(r + c8 * 32), *reinterpret_cast<const uint4*>(r + c8 * 32 + 16), rv);
+    for (int i = 0; i < 8; ++i) v[i] = (sa * cn[i]) * v[i];
+    if (p.res) {
+        const char* r = p.res + (size_t)idx * (size_t)(p.Cp * 4) + c8 * 32;
+        float rv[8];
+        join8(*reinterpret_cast<const uint4*>(r), *reinterpret_cast<const uint4*>(r + 16), rv);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += rv[i];
-        }
-        if (p.relu) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-        }
-        uint4 hi, lo;
-        split8(v, hi, lo);
-        *reinterpret_cast<uint4*>(o + c8 * 32) = hi;
-        *reinterpret_cast<uint4*>(o + c8 * 32 + 16) = lo;
+        for (int i = 0; i < 8; ++i) v[i] += rv[i];
     }
+    if (p.relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    uint4 hi, lo;
+    split8(v, hi, lo);
+    char* o = p.y + (size_t)idx * (size_t)p.y_pix_bytes + ((p.y_c0 >> 3) + c8) * 32;
+    *reinterpret_cast<uint4*>(o) = hi;
+    *reinterpret_cast<uint4*>(o + 16) = lo;
 }
 
 // ---- resample_slice: thread = (dst pixel, 8-channel group of the source) ---------------------------------
@@ -232,15 +251,18 @@ int launch_ca_mlp(const float* partial, const float* w0, const float* w2, float*
 }
 
 int launch_cbam_maps(const char* x, const float* ca, float* maps, int N, int HW, int C, int Cp, hipStream_t s) {
-    const long long total = (long long)N * HW;
-    hipLaunchKernelGGL(cbam_maps_kernel, dim3(blocks(total)), dim3(256), 0, s, x, ca, maps, total, HW, C, Cp);
+    const long long npix = (long long)N * HW;
+    if ((Cp & 7) || Cp > 2048 || Cp < 8) return (int)hipErrorInvalidValue;
+    const int ppb = 256 / (Cp >> 3);
+    hipLaunchKernelGGL(cbam_maps_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, s, x, ca, maps, npix, HW, C, Cp);
     return (int)hipGetLastError();
 }
 
 int launch_cbam_apply(const CbamApplyParams& p, hipStream_t s) {
-    const long long total = (long long)p.N * p.H * p.W;
-    if ((p.y_c0 & 7) || (p.Cp & 7)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(cbam_apply_kernel, dim3(blocks(total)), dim3(256), 0, s, p, total);
+    const long long npix = (long long)p.N * p.H * p.W;
+    if ((p.y_c0 & 7) || (p.Cp & 7) || p.Cp > 2048 || p.Cp < 8) return (int)hipErrorInvalidValue;
+    const int ppb = 256 / (p.Cp >> 3);
+    hipLaunchKernelGGL(cbam_apply_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, s, p, npix);
     return (int)hipGetLastError();
 }
 
