@@ -127,6 +127,10 @@ int launch_zero_slice(char* y, long long npix, int y_pix_bytes, int c0, int ncha
 // ---- arg-max + log-quadratic refine (keypoints.hip) ----------------------------------------
 int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, hipStream_t stream);
 
+// ---- crop + edge-pad + 8-bit bilinear resize + normalise: u8 frames -> f32 [N][1][S][S] (crops.hip) ----
+int launch_crops(const unsigned char* frames, const int* boxes, float* out, int N, int FH, int FW, int S,
+                 float mean, float std_, hipStream_t s);
+
 // ---- layout conversion f32 NCHW <-> SB (layout.hip) ----------------------------------------
 int launch_nchw_to_sb(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s);
 int launch_sb_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s);

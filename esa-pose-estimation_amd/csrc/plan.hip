@@ -1169,6 +1169,16 @@ int esahrnet_keypoints(const void* heat_dev, int n, int k, int height, int width
     return 0;
 }
 
+int esahrnet_crops(const void* frames_dev, int n, int frame_h, int frame_w, const void* boxes_dev, int scale,
+                   float mean, float stdv, void* out_dev, esahrnet_stream stream) {
+    if (!frames_dev || !boxes_dev || !out_dev || n <= 0 || scale <= 0 || !(stdv > 0.f)) return fail("crops: bad argument");
+    const int rc = esa::launch_crops(static_cast<const unsigned char*>(frames_dev), static_cast<const int*>(boxes_dev),
+                                     static_cast<float*>(out_dev), n, frame_h, frame_w, scale, mean, stdv,
+                                     static_cast<hipStream_t>(stream));
+    if (rc) return fail("crops: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
 int esahrnet_flops_per_crop(esahrnet_handle h, int height, int width, double* flops) {
     if (!h || !flops) return fail("flops_per_crop: null argument");
     std::vector<int> lh, lw;

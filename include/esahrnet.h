@@ -102,6 +102,13 @@ int esahrnet_forward(esahrnet_handle h, const void* x_dev, int n, int height, in
 int esahrnet_keypoints(const void* heat_dev, int n, int k, int height, int width,
                        void* kp_dev, esahrnet_stream stream);
 
+/* Loader stage in front of the path (data_load_val.py:139-187): for each of n 8-bit frames
+ * [frame_h][frame_w] take the clamped box boxes[i] = (x0, y0, x1, y1) (int32, device), edge-pad it the
+ * way the reference does, resize to scale x scale (OpenCV 8-bit INTER_LINEAR arithmetic) and write
+ * (v/255 - mean)/std into out_dev f32 [n][1][scale][scale] — the tensor esahrnet_forward takes. */
+int esahrnet_crops(const void* frames_dev, int n, int frame_h, int frame_w, const void* boxes_dev, int scale,
+                   float mean, float stdv, void* out_dev, esahrnet_stream stream);
+
 /* ---- introspection / per-operator entry points (used by the parity tests) ------------- */
 
 /* Algorithmic (direct-convolution) FLOPs of one forward of one crop: 2 * MACs of every conv. */
