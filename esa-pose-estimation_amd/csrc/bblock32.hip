@@ -208,7 +208,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void bblock32_kernel(BlockParams p, in
                 for (int m = 0; m < 2; ++m) {
                     float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = inside ? fmaxf(acc1[k][m][i], 0.f) : 0.f;
+                    for (int i = 0; i < 4; ++i) v[i] = inside ? relu1(acc1[k][m][i]) : 0.f;
                     uint2 hi, lo;
                     split4(v, hi, lo);
                     // channels m*16 + g*4 .. +3  ->  8-channel group c8 = 2m + (g>>1), half g&1
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void bblock32_kernel(BlockParams p, in
                     char* o = p.y + ((size_t)(n * p.H + oy) * p.W + ox) * 128 + (co >> 3) * 32 + ((co >> 2) & 1) * 8;
                     float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc2[m][t][i], 0.f);
+                    for (int i = 0; i < 4; ++i) v[i] = relu1(acc2[m][t][i]);
                     uint2 hi, lo;
                     split4(v, hi, lo);
                     *reinterpret_cast<uint2*>(o) = hi;

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
                     float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
                     if (p.relu) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                        for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
                     }
                     if (p.out_f32) {
                         const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_ring_kernel(ConvParams 
                 float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
                 if (p.relu) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
                 }
                 if (p.out_f32) {
                     const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
@@ -504,7 +504,7 @@ int launch_tp(const ConvParams& p, hipStream_t stream) {
 
 template <int KS, int S, int TH, int MT>
 int launch_t(const ConvParams& p, hipStream_t stream) {
-    if (KS == 3 && S == 1 && p.Cinp == 32) return launch_tp<KS, S, TH, MT, true>(p, stream);
+    if (KS == 3 && p.Cinp == 32) return launch_tp<KS, S, TH, MT, true>(p, stream);
 #if ESA_CONV_RING
     if constexpr (KS == 3) {
         if (p.Cinp > 32) return launch_ring<S, TH, MT>(p, stream);

@@ -192,8 +192,8 @@ __global__ __launch_bounds__(HTHREADS, 1) void head_fused_kernel(HeadParams p, i
         float v[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[i] = fmaxf(a[0][i] + s[0][i], 0.f);
-            v[4 + i] = fmaxf(a[1][i] + s[1][i], 0.f);
+            v[i] = relu1(a[0][i] + s[0][i]);
+            v[4 + i] = relu1(a[1][i] + s[1][i]);
         }
         uint4 hb, lb;
         split8(v, hb, lb);
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(HTHREADS, 1) void head_fused_kernel(HeadParams p, i
             const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;
             float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc3[m][i] + bv[i], 0.f);
+            for (int i = 0; i < 4; ++i) v[i] = relu1(acc3[m][i] + bv[i]);
             uint2 hi, lo;
             split4(v, hi, lo);
             *reinterpret_cast<uint2*>(o + cofs) = hi;

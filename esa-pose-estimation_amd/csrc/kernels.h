@@ -100,6 +100,36 @@ bool head_fused_supported(int H, int W, const int th[3], const int tw[3], int C0
 size_t head_w3_bytes(int K, int Ctp);
 void pack_head_w3(const float* w, int K, int Ct, int Ctp, void* dst);
 
+// ---- second-generation fused head: bilinear up-sampling on the matrix cores (head_t.hip, head_fused2.hip)
+constexpr int HT_PAD = 1;       // T layout: stored column = x + HT_PAD
+struct HeadTParams {
+    const char* x;      // SB [N][h][w][Cinp]                      branch b activations
+    char* t;            // T layout [N][h][Ctp/32][hi|lo][32][XP] bf16   t_b = W_b * x_b
+    const uint4* wt;    // packed [Ctp/16][Cinp/32][hi|lo][64]     (pack_conv_weights, k = 1)
+    int N, h, w, Cinp, Ctp, XP;
+};
+int launch_head_t(const HeadTParams& p, hipStream_t stream);
+int head_t_xp(int w);                       // row pitch (pixels) of the T layout for a w-pixel row
+bool head_t_supported(int Cinp);
+struct Head2Params {
+    const char* x0;     // SB [N][H][W][C0p]            stage-4 branch 0
+    const char* x1;     // SB [N][th0][tw0][C1p]        stage-4 branch 1
+    const char* t2;     // T layout, branch 2
+    const char* t3;     // T layout, branch 3
+    char* y;            // SB [N][H][W][C3p]
+    const uint4* w0;    // packed [Ctp/16][C0p/32][hi|lo][64]
+    const uint4* w1;    // packed [Ctp/16][C1p/32][hi|lo][64]
+    const uint4* w3;    // packed [M3][Ctp/32][hi|lo][64]  (pack_head_w3)
+    const float* bias0; // f32 [Ctp]
+    const float* bias3; // f32 [C3p]
+    int N, H, W;
+    int th[3], tw[3];   // grids of branches 1..3
+    int xp2, xp3;       // T-layout row pitches
+    int C0p, C1p, Ctp, C3p, K;
+};
+int launch_head2(const Head2Params& p, bool ulo, hipStream_t stream);
+bool head_fused2_supported(int H, int W, const int th[3], const int tw[3], int C0p, int C1p, int K, bool* ulo);
+
 // ---- CBAM attention of the seg_hrnet3 variant + slice re-sampling (cbam.hip) --------------------
 int launch_pool_partial(const char* x, float* partial, int N, int HW, int Cp, int P, hipStream_t s);
 int launch_ca_mlp(const float* partial, const float* w0, const float* w2, float* ca, int N, int HW, int C,

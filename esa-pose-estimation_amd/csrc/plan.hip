@@ -70,7 +70,7 @@ struct DevConv {                // one MFMA convolution launch (a ConvSpec or a 
     float* bias = nullptr;      // device, f32 [coutp]
 };
 
-enum OpKind { OP_STEM, OP_STEMF, OP_CONV, OP_BLOCK, OP_FUSE, OP_HEAD, OP_FINAL,
+enum OpKind { OP_STEM, OP_STEMF, OP_CONV, OP_BLOCK, OP_FUSE, OP_HEAD, OP_HEADT, OP_HEAD2, OP_FINAL,
               // seg_hrnet3 (CBAM) variant only:
               OP_STEMRAW, OP_POOL, OP_MLP, OP_MAPS, OP_APPLY, OP_RESAMPLE, OP_ZERO, OP_TONCHW };
 
@@ -86,6 +86,8 @@ struct Tensor {
     int C, Cp, level;
     int flat = 0;               // > 0: plain f32 scratch of `flat` floats per sample (no spatial extent)
     std::string tap;            // name for esahrnet_tap_read, "" if anonymous
+    bool tlayout = false;       // head term in the transposed T layout (head_t.hip): row pitch head_t_xp(w)
+    int alt = 0;                // 0: always; 1 / 2: only when the first / second generation head runs
     int def = -1, last = -1;    // op indices
     size_t off = 0;             // per-shape plan
 };
@@ -103,6 +105,7 @@ struct Op {
     int c0 = 0;                 // channel offset inside `out` (OP_APPLY / OP_RESAMPLE / OP_ZERO)
     int nchan = 0;              // OP_ZERO: channels to clear;  OP_RESAMPLE/OP_APPLY/OP_MAPS: real channels
     int align = 0;              // OP_RESAMPLE: align_corners
+    int alt = 0;                // 0: always; 1: head_fused path only; 2: head_fused2 path only (chosen per shape)
 };
 
 struct ShapePlan {
@@ -110,6 +113,8 @@ struct ShapePlan {
     bool keep = false;
     size_t bytes = 0;
     std::vector<int> lh, lw;    // resolution per level
+    bool head2 = false;         // this shape runs the second-generation head (ops with alt == 2)
+    bool head2_ulo = false;     // ... with the lo part of the interpolation weights
 };
 
 }  // namespace
@@ -132,6 +137,8 @@ struct esahrnet_ctx {
     bool committed = false;
     bool keep = false;
     bool fuse_big = true;       // fused stem + fused head (ESAHRNET_UNFUSED=1 selects the op-by-op plan)
+    bool head2_enabled = true;  // ESAHRNET_HEAD_V1=1 keeps the first-generation fused head for every shape
+    int head2_op = -1;          // index of the OP_HEAD2 op, -1 if the plan has none
     // optional multi-stream execution of independent branches (ESAHRNET_STREAMS=4 enables)
     int nlanes = 1;             // measured on MI355X (round 1): 4 lanes are SLOWER (4.42 vs 4.03 ms), see DESIGN.md
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
@@ -439,13 +446,22 @@ int build_plan(esahrnet_ctx& c) {
         // t_b = W_b x_b on branch b's grid (f32 NHWC), b = 1..3; W_0, bias, ReLU, last_layer[3..5]
         // and the up-sampling of the t_b all happen inside head_fused.hip
         c.spec_l0 = l0; c.spec_l3 = l3; c.head_c0 = pre[0];
-        Op o; o.kind = OP_HEAD; o.in = ys[0]; o.nterms = 3;
+        // Two alternatives, chosen per input shape (plan_shape): alt 2 = head_t.hip + head_fused2.hip
+        // (interpolation on the matrix cores, t_1 never materialised) when its geometry checks pass,
+        // alt 1 = f32 NHWC terms + head_fused.hip otherwise.  Both read the same packed W_b slices.
+        const bool have2 = c.head2_enabled && (pad32(pre[1]) == 64 || pad32(pre[1]) == 96) &&
+                           esa::head_t_supported(pad32(pre[2])) && esa::head_t_supported(pad32(pre[3]));
+        Op o; o.kind = OP_HEAD; o.in = ys[0]; o.nterms = 3; o.alt = have2 ? 1 : 0;
         int off = pre[0];
+        int dslice[4] = {-1, -1, -1, -1};
         for (int b = 1; b < 4; ++b) {
             const int save = c.specs[l0].level;
             c.specs[l0].level = 1 + b;
             B.lane = b;
             o.terms[b - 1] = B.conv(l0, ys[b], -1, false, "", off, off + pre[b], false, true);
+            c.ops.back().alt = o.alt;
+            c.tensors[o.terms[b - 1]].alt = o.alt;
+            dslice[b] = c.ops.back().dconv;
             B.lane = 0;
             c.specs[l0].level = save;
             off += pre[b];
@@ -457,6 +473,23 @@ int build_plan(esahrnet_ctx& c) {
         for (int i = 0; i < 3; ++i) B.use(o.terms[i], idx);
         c.ops.push_back(o);
         h3 = o.out;
+        if (have2) {
+            int tt[4] = {-1, -1, -1, -1};
+            for (int b = 2; b < 4; ++b) {
+                Op t; t.kind = OP_HEADT; t.in = ys[b]; t.dconv = dslice[b]; t.alt = 2;
+                t.out = B.tensor(tot, 1 + b);
+                c.tensors[t.out].tlayout = true;
+                c.tensors[t.out].alt = 2;
+                B.lane = b;
+                B.push(t);
+                B.lane = 0;
+                tt[b] = t.out;
+            }
+            Op q; q.kind = OP_HEAD2; q.in = ys[0]; q.nterms = 3; q.alt = 2; q.dconv = dslice[1];
+            q.terms[0] = ys[1]; q.terms[1] = tt[2]; q.terms[2] = tt[3];
+            q.out = h3;
+            c.head2_op = B.push(q);
+        }
     } else {
         std::vector<int> hterms;
         int off = 0;
@@ -495,6 +528,20 @@ int check_shape(const esahrnet_ctx& c, int n, int h, int w) {
     return 0;
 }
 
+// does this input shape run the second-generation head (ops with alt == 2)?
+bool head2_for_shape(const esahrnet_ctx& c, const std::vector<int>& lh, const std::vector<int>& lw, bool* ulo) {
+    if (c.head2_op < 0 || !c.head2_enabled) return false;
+    const Op& o = c.ops[c.head2_op];
+    int th[3], tw[3];
+    for (int i = 0; i < 3; ++i) {
+        const int lv = c.tensors[o.terms[i]].level;
+        th[i] = lh[lv]; tw[i] = lw[lv];
+    }
+    const Tensor& t0 = c.tensors[o.in];
+    return esa::head_fused2_supported(lh[t0.level], lw[t0.level], th, tw, t0.Cp, c.tensors[o.terms[0]].Cp,
+                                      c.cfg.num_keypoints, ulo);
+}
+
 // first-fit interval allocator over op order; tensors die after their last use
 int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
     if (c.sp.n == n && c.sp.h == h && c.sp.w == w && c.sp.keep == c.keep) return 0;
@@ -502,11 +549,14 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
     ShapePlan sp;
     sp.n = n; sp.h = h; sp.w = w; sp.keep = c.keep;
     level_dims(c, h, w, sp.lh, sp.lw);
+    sp.head2 = head2_for_shape(c, sp.lh, sp.lw, &sp.head2_ulo);
+    const int active_alt = sp.head2 ? 2 : 1;
     struct Free { size_t off, len; };
     std::vector<Free> free_list;
     size_t top = 0;
     auto bytes_of = [&](const Tensor& t) {
-        size_t b = t.flat ? (size_t)n * t.flat * 4 : (size_t)n * sp.lh[t.level] * sp.lw[t.level] * t.Cp * 4;
+        const size_t wpix = t.tlayout ? (size_t)esa::head_t_xp(sp.lw[t.level]) : (size_t)sp.lw[t.level];
+        size_t b = t.flat ? (size_t)n * t.flat * 4 : (size_t)n * sp.lh[t.level] * wpix * t.Cp * 4;
         return (b + 255) & ~(size_t)255;
     };
     auto alloc = [&](size_t len) {
@@ -556,9 +606,12 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
     struct Retired { size_t off, len; int tensor; };
     std::vector<Retired> retired;
     size_t high = 0;
+    std::vector<char> allocated(c.tensors.size(), 0);
     for (size_t oi = 0; oi < nops; ++oi) {
         const Op& o = c.ops[oi];
-        if (o.out >= 0 && c.tensors[o.out].def == (int)oi) {     // (slice writers re-use the allocation)
+        const bool active = o.alt == 0 || o.alt == active_alt;
+        if (active && o.out >= 0 && !allocated[o.out]) {         // (slice writers re-use the allocation)
+            allocated[o.out] = 1;
             const size_t len = bytes_of(c.tensors[o.out]);
             const size_t off = alloc(len);
             c.tensors[o.out].off = off;
@@ -570,7 +623,7 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
         if (!c.keep)
             for (size_t ti = 0; ti < c.tensors.size(); ++ti) {
                 Tensor& t = c.tensors[ti];
-                if (t.def >= 0 && t.def <= (int)oi && t.last == (int)oi) {
+                if (allocated[ti] && t.last == (int)oi) {
                     release(t.off, bytes_of(t));
                     retired.push_back({t.off, bytes_of(t), (int)ti});
                 }
@@ -658,6 +711,7 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     c->device = device;
     if (const char* e = getenv("ESAHRNET_UNFUSED")) c->fuse_big = !(e[0] && e[0] != '0');
     if (const char* e = getenv("ESAHRNET_STREAMS")) c->nlanes = atoi(e) > 1 ? 4 : 1;
+    if (const char* e = getenv("ESAHRNET_HEAD_V1")) c->head2_enabled = !(e[0] && e[0] != '0');
     if (build_plan(*c)) { delete c; return 1; }
     *out = c;
     return 0;
@@ -853,8 +907,14 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
     }
     bool lane_used[4] = {true, false, false, false};
     if (multi) HIP_OK(hipEventRecord(h->entry_event, caller));
+    const int active_alt = sp.head2 ? 2 : 1;
     for (const Op& o : h->ops) {
         int rc = 0;
+        if (o.alt != 0 && o.alt != active_alt) {         // the head alternative not used at this shape
+            ++op_index;
+            if (events && hipEventRecord(events[op_index], stream) != hipSuccess) return fail("forward: hipEventRecord failed");
+            continue;
+        }
         if (multi) {
             stream = o.lane == 0 ? caller : h->side[o.lane - 1];
             if (!lane_used[o.lane]) {
@@ -993,6 +1053,36 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 rc = esa::launch_head(p, stream);
                 break;
             }
+            case OP_HEADT: {
+                const Tensor& ti = h->tensors[o.in];
+                const Tensor& to = h->tensors[o.out];
+                const DevConv& d = h->dconvs[o.dconv];
+                esa::HeadTParams p{};
+                p.x = T(o.in); p.t = T(o.out); p.wt = static_cast<const uint4*>(d.w);
+                p.N = n; p.h = sp.lh[ti.level]; p.w = sp.lw[ti.level];
+                p.Cinp = ti.Cp; p.Ctp = to.Cp; p.XP = esa::head_t_xp(p.w);
+                rc = esa::launch_head_t(p, stream);
+                break;
+            }
+            case OP_HEAD2: {
+                const Tensor& ti = h->tensors[o.in];
+                const Tensor& to = h->tensors[o.out];
+                esa::Head2Params p{};
+                p.x0 = T(o.in); p.x1 = T(o.terms[0]); p.t2 = T(o.terms[1]); p.t3 = T(o.terms[2]); p.y = T(o.out);
+                p.w0 = static_cast<const uint4*>(h->head_w0); p.w3 = static_cast<const uint4*>(h->head_w3);
+                p.w1 = static_cast<const uint4*>(h->dconvs[o.dconv].w);
+                p.bias0 = h->head_b0; p.bias3 = h->head_b3;
+                p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level];
+                for (int i = 0; i < 3; ++i) {
+                    const Tensor& tt = h->tensors[o.terms[i]];
+                    p.th[i] = sp.lh[tt.level]; p.tw[i] = sp.lw[tt.level];
+                }
+                p.xp2 = esa::head_t_xp(p.tw[1]); p.xp3 = esa::head_t_xp(p.tw[2]);
+                p.C0p = ti.Cp; p.C1p = h->tensors[o.terms[0]].Cp; p.Ctp = h->tensors[o.terms[1]].Cp;
+                p.C3p = to.Cp; p.K = h->cfg.num_keypoints;
+                rc = esa::launch_head2(p, sp.head2_ulo, stream);
+                break;
+            }
             case OP_FUSE: {
                 const Tensor& to = h->tensors[o.out];
                 esa::FuseParams p{};
@@ -1074,9 +1164,17 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
     level_dims(*h, height, width, lh, lw);
     memset(out, 0, sizeof *out);
     const Op& o = h->ops[index];
+    if (o.alt != 0) {        // a head alternative: described only for the shapes that run it (else kernel = "")
+        bool ulo = false;
+        if (o.alt != (head2_for_shape(*h, lh, lw, &ulo) ? 2 : 1)) {
+            snprintf(out->label, sizeof out->label, "(not used at this shape)");
+            return 0;
+        }
+    }
     auto tbytes = [&](int t) {
         const Tensor& x = h->tensors[t];
-        return x.flat ? (double)n * x.flat * 4.0 : (double)n * lh[x.level] * lw[x.level] * x.Cp * 4.0;
+        const double wpix = x.tlayout ? (double)esa::head_t_xp(lw[x.level]) : (double)lw[x.level];
+        return x.flat ? (double)n * x.flat * 4.0 : (double)n * lh[x.level] * wpix * x.Cp * 4.0;
     };
     switch (o.kind) {
         case OP_STEM: {
@@ -1128,6 +1226,30 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             snprintf(out->kernel, sizeof out->kernel, "head_fused");
             snprintf(out->label, sizeof out->label, "last_layer.0[:, 0:%d] + up + last_layer.3", h->head_c0);
             out->flops = 2.0 * n * lh[to.level] * lw[to.level] * ((double)s0.cout * h->head_c0 + (double)s3.cout * s3.cin);
+            out->bytes = tbytes(o.in) + tbytes(o.out);
+            for (int i = 0; i < 3; ++i) out->bytes += tbytes(o.terms[i]);
+            break;
+        }
+        case OP_HEADT: {
+            const DevConv& d = h->dconvs[o.dconv];
+            const ConvSpec& s = h->specs[d.spec];
+            const Tensor& ti = h->tensors[o.in];
+            snprintf(out->kernel, sizeof out->kernel, "head_t");
+            snprintf(out->label, sizeof out->label, "%s[:, %d:%d] (T layout)", s.name.c_str(), d.c0, d.c1);
+            out->flops = 2.0 * n * lh[ti.level] * lw[ti.level] * s.cout * (d.c1 - d.c0);
+            out->bytes = tbytes(o.in) + tbytes(o.out) + (double)esa::packed_weight_bytes(d.coutp, d.cinp, 1);
+            break;
+        }
+        case OP_HEAD2: {
+            const ConvSpec& s0 = h->specs[h->spec_l0];
+            const ConvSpec& s3 = h->specs[h->spec_l3];
+            const DevConv& d1 = h->dconvs[o.dconv];
+            const Tensor& to = h->tensors[o.out];
+            const Tensor& t1 = h->tensors[o.terms[0]];
+            snprintf(out->kernel, sizeof out->kernel, "head_fused2");
+            snprintf(out->label, sizeof out->label, "last_layer.0[:, 0:%d] + up (MFMA) + last_layer.3", d1.c1);
+            out->flops = 2.0 * n * lh[to.level] * lw[to.level] * ((double)s0.cout * h->head_c0 + (double)s3.cout * s3.cin) +
+                         2.0 * n * lh[t1.level] * lw[t1.level] * (double)s0.cout * (d1.c1 - d1.c0);
             out->bytes = tbytes(o.in) + tbytes(o.out);
             for (int i = 0; i < 3; ++i) out->bytes += tbytes(o.terms[i]);
             break;

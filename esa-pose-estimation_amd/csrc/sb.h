@@ -31,13 +31,32 @@ __device__ __forceinline__ void split_bf16(float v, uint32_t& hi, uint32_t& lo) 
     lo = (uint32_t)__builtin_bit_cast(unsigned short, l);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// Two floats -> one dword of hi bf16 (a in the low half) + one dword of lo bf16: v_cvt_pk_bf16_f32 on
+// the pair, the residuals against the packed hi halves, v_cvt_pk_bf16_f32 again (6 VALU ops per pair;
+// same round-to-nearest-even results as split_bf16 element by element).
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {a, b};
+    const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {a - __uint_as_float(hb << 16), b - __uint_as_float(hb & 0xffff0000u)};
+    hi = hb;
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+}
+
+// max(v, 0) in one instruction: as signed integers every negative float (and -0) is < 0 and the
+// non-negative floats keep their order, so v_max_i32 against 0 is ReLU (fmaxf costs a second,
+// canonicalising v_max for values the compiler cannot prove quiet, e.g. MFMA results).
+__device__ __forceinline__ float relu1(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 // 4 floats -> 8 bytes of hi bf16 + 8 bytes of lo bf16
 __device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
-    uint32_t h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split_bf16(v[i], h[i], l[i]);
-    hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    split2(v[0], v[1], hi.x, lo.x);
+    split2(v[2], v[3], hi.y, lo.y);
 }
 
 __device__ __forceinline__ void join4(uint2 hi, uint2 lo, float v[4]) {

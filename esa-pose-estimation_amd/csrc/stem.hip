@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, long long total
     }
     if (p.relu) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = fmaxf(acc[i], 0.f);
+        for (int i = 0; i < 8; ++i) acc[i] = relu1(acc[i]);
     }
     uint4 hi, lo;
     split8(acc, hi, lo);

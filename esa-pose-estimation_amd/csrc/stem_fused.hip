@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void stem_fused_kernel(StemFusedParams
             for (int it = 0; it < QIT; ++it) {
                 const int q = lane + it * 64;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) a[it][i] = inside[it] ? fmaxf(a[it][i], 0.f) : 0.f;
+                for (int i = 0; i < 8; ++i) a[it][i] = inside[it] ? relu1(a[it][i]) : 0.f;
                 uint4 hi, lo;
                 split8(a[it], hi, lo);
                 if (q < SC::NPIX) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void stem_fused_kernel(StemFusedParams
             const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;
             float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[k][m][i], 0.f);
+            for (int i = 0; i < 4; ++i) v[i] = relu1(acc[k][m][i]);
             uint2 hi, lo;
             split4(v, hi, lo);
             char* o = p.y + ((size_t)(n * p.OH + oy) * p.OW + ox) * (size_t)(p.Coutp * 4) + cofs;

@@ -289,6 +289,8 @@ class _Runtime:
         for i in range(nops):
             d = _lib.OpDesc()
             _lib.check(self.lib.esahrnet_op_desc_get(h, i, n, hh, ww, C.byref(d)))
+            if not d.kernel:        # a plan alternative that this shape does not run (esahrnet.h: op_desc_get)
+                continue
             ops.append(dict(kernel=d.kernel.decode(), label=d.label.decode(), ms=float(ms[i]),
                             flops=d.flops, bytes=d.bytes))
         return heat, ops
