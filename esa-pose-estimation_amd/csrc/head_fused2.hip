@@ -26,16 +26,34 @@
 #include "kernels.h"
 #include "sb.h"
 
+// ablation switches for tuning experiments (all 1 in the shipped build)
+#ifndef H2_DO_T1
+#define H2_DO_T1 1
+#endif
+#ifndef H2_DO_INTERP
+#define H2_DO_INTERP 1
+#endif
+#ifndef H2_DO_W0
+#define H2_DO_W0 1
+#endif
+#ifndef H2_DO_W3
+#define H2_DO_W3 1
+#endif
+#ifndef H2_NW
+#define H2_NW 8                 // waves (= output rows) per workgroup: 8 -> two workgroups per CU
+#endif
+#ifndef H2_DO_BAR
+#define H2_DO_BAR 1
+#endif
+
 namespace esa {
 namespace {
 
-constexpr int HT = 16;
-constexpr int H2THREADS = 1024;
-constexpr int R1 = 11, R2 = 7, R3 = 5;          // max source rows per branch and tile
-constexpr int T1OFF = 0;
-constexpr int T2OFF = R1 * 2 * 1024;
-constexpr int T3OFF = T2OFF + R2 * 1024;
-constexpr int TBUF = T3OFF + R3 * 1024;         // 34816 B
+constexpr int HTW = 16;                         // tile width = one MFMA N-tile; tile height = waves per workgroup
+// max source rows per branch and tile of NW output rows (2x / 4x / 8x coarser grids, +3 for the taps)
+constexpr int rows1(int nw) { return nw / 2 + 3; }
+constexpr int rows2(int nw) { return nw / 4 + 3; }
+constexpr int rows3(int nw) { return nw / 8 + 3; }
 
 struct Lerp2 {
     int i0, i1;
@@ -53,13 +71,17 @@ __device__ __host__ inline Lerp2 lerp2(int dst, int in, int out) {     // ATen a
     return r;
 }
 
-template <int NCH0, int NCH1, int M3, bool ULO>
-__global__ __launch_bounds__(H2THREADS, 1) void head_fused2_kernel(Head2Params p, int tiles_x, int tiles_y) {
+template <int NW, int NCH0, int NCH1, int M3, bool ULO>
+__global__ __launch_bounds__(NW * 64, 4) void head_fused2_kernel(Head2Params p, int tiles_x, int tiles_y) {
+    constexpr int H2THREADS = NW * 64;
+    constexpr int R1 = rows1(NW), R2 = rows2(NW), R3 = rows3(NW);
+    constexpr int T1OFF = 0, T2OFF = R1 * 2 * 1024, T3OFF = T2OFF + R2 * 1024, TBUF = T3OFF + R3 * 1024;
     constexpr int W03FR = 4 * NCH0 + 2 * M3;             // W0 then W3 fragments of one chunk
     constexpr int W03S = W03FR * 1024 + 256;             // + 32 bias floats
     constexpr int W1FR = 4 * NCH1;
     constexpr int W1S = W1FR * 1024;
-    static_assert(W03FR < 16 && W1FR <= 16, "one weight fragment per wave");
+    constexpr int WLD = (W03FR + 1 + NW - 1) / NW;       // W0/W3/bias items per wave and chunk
+    constexpr int W1LD = (W1FR + NW - 1) / NW;           // W_1 fragments per wave and chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const tb0 = smem;
     char* const w03b = smem + 2 * TBUF;
@@ -70,75 +92,95 @@ __global__ __launch_bounds__(H2THREADS, 1) void head_fused2_kernel(Head2Params p
     const int tx = b_ % tiles_x; b_ /= tiles_x;
     const int ty = b_ % tiles_y;
     const int n = b_ / tiles_y;
-    const int oy0 = ty * HT, ox0 = tx * HT;
+    const int oy0 = ty * NW, ox0 = tx * HTW;
+#ifdef H2_NCHUNKS
+    const int nchunks = H2_NCHUNKS;         // timing experiments only
+#else
     const int nchunks = p.Ctp >> 5;
+#endif
 
     // ---- source windows of the three low-resolution branches (workgroup-uniform) ---------------
     int ry0[3], rh[3], ws[3], rw0;
     {
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-            const Lerp2 a = lerp2(oy0, p.th[b], p.H), e = lerp2(min(oy0 + HT - 1, p.H - 1), p.th[b], p.H);
+            const Lerp2 a = lerp2(oy0, p.th[b], p.H), e = lerp2(min(oy0 + NW - 1, p.H - 1), p.th[b], p.H);
             const Lerp2 c = lerp2(ox0, p.tw[b], p.W);
             ry0[b] = a.i0; rh[b] = e.i1 - a.i0 + 1;
             // window slot 0 in source columns: branch 1 starts at the first needed column, branches
             // 2/3 at the 8-byte aligned stored column below it (stored column = x + HT_PAD)
             ws[b] = b == 0 ? c.i0 : ((c.i0 + HT_PAD) & ~3) - HT_PAD;
         }
-        const Lerp2 d = lerp2(min(ox0 + HT - 1, p.W - 1), p.tw[0], p.W);
+        const Lerp2 d = lerp2(min(ox0 + HTW - 1, p.W - 1), p.tw[0], p.W);
         rw0 = d.i1 - ws[0] + 1;
     }
 
-    // ---- staging map of the t_2 / t_3 windows: unit = (row, part, channel, 4-pixel half) ----------
+    // ---- staging maps.  Everything below is branch-free on purpose: every thread issues the same four
+    // loads per chunk and the same four LDS writes (threads without a unit of their own repeat another
+    // thread's — same data to the same address), so the compiler can keep two generations of loads in
+    // flight with counted waits instead of draining vmcnt at every control-flow join.
+    // t_2 / t_3 windows: unit = (row, part, channel, 4-pixel half), 8 B each
     const char* sg[2];
     int sstride[2], sdst[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const int u = it * H2THREADS + tid;
         const int n2 = rh[1] * 128, n3 = rh[2] * 128;
-        sg[it] = nullptr; sstride[it] = 0; sdst[it] = 0;
-        if (u < n2 + n3) {
-            const int b = u < n2 ? 1 : 2;
-            const int v = u < n2 ? u : u - n2;
-            const int r = v >> 7, part = (v >> 6) & 1, ch = (v >> 1) & 31, half = v & 1;
-            const int xp = b == 1 ? p.xp2 : p.xp3;
-            const char* base = b == 1 ? p.t2 : p.t3;
-            sg[it] = base + ((((size_t)n * p.th[b] + ry0[b] + r) * nchunks * 2 + part) * 32 + ch) * (size_t)(xp * 2)
-                     + (size_t)(ws[b] + HT_PAD + half * 4) * 2;
-            sstride[it] = 128 * xp;                      // bytes between chunks: 2 parts x 32 ch x XP x 2 B
-            sdst[it] = (b == 1 ? T2OFF : T3OFF) + v * 8;
-        }
+        const int u = (it * H2THREADS + tid) % (n2 + n3);
+        const int b = u < n2 ? 1 : 2;
+        const int v = u < n2 ? u : u - n2;
+        const int r = v >> 7, part = (v >> 6) & 1, ch = (v >> 1) & 31, half = v & 1;
+        const int xp = b == 1 ? p.xp2 : p.xp3;
+        const char* base = b == 1 ? p.t2 : p.t3;
+        sg[it] = base + ((((size_t)n * p.th[b] + ry0[b] + r) * nchunks * 2 + part) * 32 + ch) * (size_t)(xp * 2)
+                 + (size_t)(ws[b] + HT_PAD + half * 4) * 2;
+        sstride[it] = 128 * xp;                          // bytes between chunks: 2 parts x 32 ch x XP x 2 B
+        sdst[it] = (b == 1 ? T2OFF : T3OFF) + v * 8;
     }
-    uint2 sr[2];
-    uint4 wreg, w1reg;
+    // W0 / W3 fragments and bias0 of a chunk: item f = j*NW + wave (items past the bias item repeat it,
+    // its lanes >= 8 repeat lanes 0..7); W_1 fragments: (j*NW + wave) % W1FR
+    const uint4* wsrc[WLD];
+    int wstep[WLD], wdst[WLD];
+#pragma unroll
+    for (int j = 0; j < WLD; ++j) {
+        const int f = j * NW + wave < W03FR ? j * NW + wave : W03FR;
+        if (f < 4 * NCH0) { wsrc[j] = p.w0 + f * 64 + lane; wstep[j] = 4 * NCH0 * 64; }
+        else if (f < W03FR) { wsrc[j] = p.w3 + ((size_t)((f - 4 * NCH0) >> 1) * nchunks * 2 + ((f - 4 * NCH0) & 1)) * 64 + lane; wstep[j] = 128; }
+        else { wsrc[j] = reinterpret_cast<const uint4*>(p.bias0) + (lane & 7); wstep[j] = 8; }
+        wdst[j] = f < W03FR ? (f * 64 + lane) * 16 : W03FR * 1024 + (lane & 7) * 16;
+    }
+    const uint4* w1src[W1LD];
+    int w1dst[W1LD];
+#pragma unroll
+    for (int j = 0; j < W1LD; ++j) {
+        const int f = (j * NW + wave) % W1FR;
+        w1src[j] = p.w1 + f * 64 + lane;
+        w1dst[j] = (f * 64 + lane) * 16;
+    }
+    const int clast = nchunks - 1;
+    // two staging register sets (A, B): the loads of chunk c+2 are issued while chunk c is consumed
+    // and committed to LDS a whole iteration later — one workgroup per CU has nobody else to hide
+    // the ~2 us load latency behind.  Chunk indices past the end are clamped (a redundant reload).
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;      // (HIP's uint4 struct in an array ends up in scratch)
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    u32x2 srA[2], srB[2];
+    u32x4 wregA[WLD], w1regA[W1LD], wregB[WLD], w1regB[W1LD];
     // chunk CH: t_2/t_3 windows + W0/W3/bias0; chunk CH1: W_1 fragments
-#define H2_PREFETCH(CH, CH1)                                                                  \
+#define H2_PREFETCH(CH, CH1, S)                                                               \
     {                                                                                         \
-        if ((CH) < nchunks) {                                                                 \
-            _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                \
-                uint2 v = make_uint2(0, 0);                                                   \
-                if (sg[it]) v = *reinterpret_cast<const uint2*>(sg[it] + (size_t)(CH) * sstride[it]); \
-                sr[it] = v;                                                                   \
-            }                                                                                 \
-            if (wave < 4 * NCH0)                                                              \
-                wreg = p.w0[((size_t)(CH) * 4 * NCH0 + wave) * 64 + lane];                    \
-            else if (wave < W03FR)                                                            \
-                wreg = p.w3[((size_t)(((wave - 4 * NCH0) >> 1) * nchunks + (CH)) * 2 + ((wave - 4 * NCH0) & 1)) * 64 + lane]; \
-            else if (wave == W03FR && lane < 8)                                               \
-                wreg = *reinterpret_cast<const uint4*>(p.bias0 + (CH) * 32 + lane * 4);       \
-        }                                                                                     \
-        if ((CH1) < nchunks && wave < W1FR) w1reg = p.w1[((size_t)(CH1) * W1FR + wave) * 64 + lane]; \
+        const int ch_ = min((CH), clast), ch1_ = min((CH1), clast);                           \
+        _Pragma("unroll") for (int it = 0; it < 2; ++it)                                      \
+            sr##S[it] = *reinterpret_cast<const u32x2*>(sg[it] + (size_t)ch_ * sstride[it]);  \
+        _Pragma("unroll") for (int j = 0; j < WLD; ++j) wreg##S[j] = *reinterpret_cast<const u32x4*>(wsrc[j] + (size_t)ch_ * wstep[j]); \
+        _Pragma("unroll") for (int j = 0; j < W1LD; ++j) w1reg##S[j] = *reinterpret_cast<const u32x4*>(w1src[j] + (size_t)ch1_ * W1FR * 64); \
     }
-#define H2_COMMIT(CH, CH1)                                                                    \
+#define H2_COMMIT(CH, CH1, S)                                                                 \
     {                                                                                         \
-        if ((CH) < nchunks) {                                                                 \
-            _Pragma("unroll") for (int it = 0; it < 2; ++it)                                  \
-                if (sg[it]) *reinterpret_cast<uint2*>(tb0 + ((CH) & 1) * TBUF + sdst[it]) = sr[it]; \
-            if (wave < W03FR || (wave == W03FR && lane < 8))                                  \
-                *reinterpret_cast<uint4*>(w03b + ((CH) & 1) * W03S + tid * 16) = wreg;        \
-        }                                                                                     \
-        if ((CH1) < nchunks && wave < W1FR)                                                   \
-            *reinterpret_cast<uint4*>(w1b + ((CH1) & 1) * W1S + tid * 16) = w1reg;            \
+        _Pragma("unroll") for (int it = 0; it < 2; ++it)                                      \
+            *reinterpret_cast<u32x2*>(tb0 + ((CH) & 1) * TBUF + sdst[it]) = sr##S[it];        \
+        _Pragma("unroll") for (int j = 0; j < WLD; ++j)                                       \
+            *reinterpret_cast<u32x4*>(w03b + ((CH) & 1) * W03S + wdst[j]) = wreg##S[j];       \
+        _Pragma("unroll") for (int j = 0; j < W1LD; ++j)                                      \
+            *reinterpret_cast<u32x4*>(w1b + ((CH1) & 1) * W1S + w1dst[j]) = w1reg##S[j];      \
     }
 
     // ---- per-lane constants -------------------------------------------------------------------------
@@ -202,7 +244,7 @@ __global__ __launch_bounds__(H2THREADS, 1) void head_fused2_kernel(Head2Params p
 
     // t_1 of chunk CH (W_1 fragments of that chunk are in w1 buffer CH&1) -> T buffer CH&1
 #define H2_T1(CH)                                                                             \
-    if (t1wave) {                                                                             \
+    if (H2_DO_T1 && t1wave) {                                                                 \
         const char* wb1 = w1b + ((CH) & 1) * W1S + lane * 16;                                 \
         char* td = tb0 + ((CH) & 1) * TBUF + T1OFF + (wave * 2 + (q >> 1)) * 1024 + px * 16 + (q & 1) * 8; \
         _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                       \
@@ -226,17 +268,30 @@ __global__ __launch_bounds__(H2THREADS, 1) void head_fused2_kernel(Head2Params p
 #pragma unroll
     for (int m = 0; m < M3; ++m) acc3[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: W_1(0); then chunk 0's data + W_1(1) while t_1(0) is computed -------------------
-    H2_PREFETCH(nchunks, 0)
-    H2_COMMIT(nchunks, 0)
+    // ---- prologue: W_1(0); then chunk 0's data + W_1(1) while t_1(0) is computed; set A then takes
+    // chunk 1 + W_1(2), which iteration 0 commits ---------------------------------------------------------
+    H2_PREFETCH(0, 0, B)
+    H2_COMMIT(0, 0, B)
     __syncthreads();
-    H2_PREFETCH(0, 1)
+    H2_PREFETCH(0, 1, A)
     H2_T1(0)
-    H2_COMMIT(0, 1)
+    H2_COMMIT(0, 1, A)
     __syncthreads();
+    H2_PREFETCH(1, 2, A)
 
-    for (int cc = 0; cc < nchunks; ++cc) {
-        H2_PREFETCH(cc + 1, cc + 2)
+    // iteration cc: issue the loads of (cc+2, cc+3) into set SP, consume chunk cc, produce t_1(cc+1),
+    // commit set SC = (cc+1, cc+2) issued one iteration ago
+#define H2_ITER(SP, SC)                                                                       \
+    {                                                                                         \
+        H2_PREFETCH(cc + 2, cc + 3, SP)                                                       \
+        h2_consume(cc);                                                                       \
+        if (cc + 1 < nchunks) {                                                               \
+            H2_T1(cc + 1)                                                                     \
+            H2_COMMIT(cc + 1, cc + 2, SC)   /* nobody reads T/W03 buffer (cc+1)&1 or W_1 buffer cc&1 now */ \
+            if (H2_DO_BAR) __syncthreads();                                                   \
+        }                                                                                     \
+    }
+    auto h2_consume = [&](int cc) __attribute__((always_inline)) {
         const char* tb = tb0 + (cc & 1) * TBUF;
         const char* wb = w03b + (cc & 1) * W03S;
         f32x4 a[2];
@@ -244,7 +299,7 @@ __global__ __launch_bounds__(H2THREADS, 1) void head_fused2_kernel(Head2Params p
         a[1] = *reinterpret_cast<const f32x4*>(wb + W03FR * 1024 + 64 + q * 16);
         // (1) W0·x0
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < (H2_DO_W0 ? 2 : 0); ++m)
 #pragma unroll
             for (int c = 0; c < NCH0; ++c) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wb + lane * 16 + ((m * NCH0 + c) * 2 + 0) * 1024);
@@ -255,7 +310,7 @@ __global__ __launch_bounds__(H2THREADS, 1) void head_fused2_kernel(Head2Params p
             }
         // (2) + sum_b U_b·t_b
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc)
+        for (int kc = 0; kc < (H2_DO_INTERP ? 2 : 0); ++kc)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const bf16x8 th_ = *reinterpret_cast<const bf16x8*>(tb + offA[kc] + m * 256);
@@ -275,19 +330,20 @@ __global__ __launch_bounds__(H2THREADS, 1) void head_fused2_kernel(Head2Params p
         split8(v, hb, lb);
         const bf16x8 hh = __builtin_bit_cast(bf16x8, hb), hl = __builtin_bit_cast(bf16x8, lb);
 #pragma unroll
-        for (int m = 0; m < M3; ++m) {
+        for (int m = 0; m < (H2_DO_W3 ? M3 : 0); ++m) {
             const bf16x8 a3h = *reinterpret_cast<const bf16x8*>(wb + lane * 16 + (4 * NCH0 + m * 2 + 0) * 1024);
             const bf16x8 a3l = *reinterpret_cast<const bf16x8*>(wb + lane * 16 + (4 * NCH0 + m * 2 + 1) * 1024);
             acc3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3l, hh, acc3[m], 0, 0, 0);
             acc3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3h, hl, acc3[m], 0, 0, 0);
             acc3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3h, hh, acc3[m], 0, 0, 0);
         }
-        if (cc + 1 < nchunks) {
-            H2_T1(cc + 1)
-            H2_COMMIT(cc + 1, cc + 2)       // nobody reads T/W03 buffer (cc+1)&1 or W_1 buffer cc&1 now
-            __syncthreads();
-        }
+    };
+    for (int cc = 0; cc < nchunks; ++cc) {
+        H2_ITER(B, A)
+        if (++cc >= nchunks) break;
+        H2_ITER(A, B)
     }
+#undef H2_ITER
 #undef H2_PREFETCH
 #undef H2_COMMIT
 #undef H2_T1
@@ -316,27 +372,29 @@ __global__ __launch_bounds__(H2THREADS, 1) void head_fused2_kernel(Head2Params p
     }
 }
 
-template <int NCH0, int NCH1, int M3, bool ULO>
+template <int NW, int NCH0, int NCH1, int M3, bool ULO>
 int launch_head2_t(const Head2Params& p, hipStream_t stream) {
-    auto kern = head_fused2_kernel<NCH0, NCH1, M3, ULO>;
+    auto kern = head_fused2_kernel<NW, NCH0, NCH1, M3, ULO>;
     static bool attr_set = false;
-    const int lds = 2 * TBUF + 2 * ((4 * NCH0 + 2 * M3) * 1024 + 256) + 2 * 4 * NCH1 * 1024;
+    const int lds = 2 * (rows1(NW) * 2 + rows2(NW) + rows3(NW)) * 1024 + 2 * ((4 * NCH0 + 2 * M3) * 1024 + 256) +
+                    2 * 4 * NCH1 * 1024;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int tiles_x = (p.W + HT - 1) / HT, tiles_y = (p.H + HT - 1) / HT;
+    const int tiles_x = (p.W + HTW - 1) / HTW, tiles_y = (p.H + NW - 1) / NW;
     const long long nblk = (long long)p.N * tiles_x * tiles_y;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(H2THREADS), lds, stream, p, tiles_x, tiles_y);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NW * 64), lds, stream, p, tiles_x, tiles_y);
     return (int)hipGetLastError();
 }
 
 template <int NCH0, int NCH1, int M3>
 int launch_head2_u(const Head2Params& p, bool ulo, hipStream_t stream) {
-    return ulo ? launch_head2_t<NCH0, NCH1, M3, true>(p, stream) : launch_head2_t<NCH0, NCH1, M3, false>(p, stream);
+    return ulo ? launch_head2_t<H2_NW, NCH0, NCH1, M3, true>(p, stream)
+               : launch_head2_t<H2_NW, NCH0, NCH1, M3, false>(p, stream);
 }
 
 inline bool bf16_exact(float f) {
@@ -353,16 +411,21 @@ bool head_fused2_supported(int H, int W, const int th[3], const int tw[3], int C
     if (C0p != 32 && C0p != 64) return false;
     if (C1p != 64 && C1p != 96) return false;
     if (K < 1 || K > 32) return false;
-    const int rmax[3] = {R1, R2, R3};
+    constexpr int NW = H2_NW;
+    const int rmax[3] = {rows1(NW), rows2(NW), rows3(NW)};
+    int rsum = 0;
     bool need_lo = false;
     for (int b = 0; b < 3; ++b) {
         if (th[b] < 1 || tw[b] < 1 || th[b] > H || tw[b] > W) return false;
-        for (int o = 0; o < H; o += HT) {
-            const Lerp2 a = lerp2(o, th[b], H), e = lerp2(o + HT - 1 < H - 1 ? o + HT - 1 : H - 1, th[b], H);
+        int rb = 0;
+        for (int o = 0; o < H; o += NW) {
+            const Lerp2 a = lerp2(o, th[b], H), e = lerp2(o + NW - 1 < H - 1 ? o + NW - 1 : H - 1, th[b], H);
             if (e.i1 - a.i0 + 1 > rmax[b]) return false;
+            rb = e.i1 - a.i0 + 1 > rb ? e.i1 - a.i0 + 1 : rb;
         }
-        for (int o = 0; o < W; o += HT) {
-            const Lerp2 c = lerp2(o, tw[b], W), d = lerp2(o + HT - 1 < W - 1 ? o + HT - 1 : W - 1, tw[b], W);
+        if (b > 0) rsum += rb;
+        for (int o = 0; o < W; o += HTW) {
+            const Lerp2 c = lerp2(o, tw[b], W), d = lerp2(o + HTW - 1 < W - 1 ? o + HTW - 1 : W - 1, tw[b], W);
             const int ws = b == 0 ? c.i0 : ((c.i0 + HT_PAD) & ~3) - HT_PAD;
             if (d.i1 - ws + 1 > (b == 0 ? 16 : 8)) return false;
         }
@@ -377,6 +440,7 @@ bool head_fused2_supported(int H, int W, const int th[3], const int tw[3], int C
             }
         }
     }
+    if (rsum * 128 > 2 * NW * 64) return false;      // t_2 + t_3 staging units: two per thread
     if (ulo) *ulo = need_lo;
     return true;
 }
