@@ -47,6 +47,9 @@
 #ifndef ESA_DO_STORE
 #define ESA_DO_STORE 1
 #endif
+#ifndef ESA_XCD_REMAP
+#define ESA_XCD_REMAP 1
+#endif
 #ifndef ESA_CONV_RING
 #define ESA_CONV_RING 1         // weight-thirds ring for 3x3 convs with >= 2 input chunks
 #endif
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
     // (PERSIST = false: one item per workgroup, same code with the cross-item prefetch compiled out.)
     const int G = gridDim.x;
     int item = blockIdx.x;
-    if ((G & 7) == 0) item = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    if (ESA_XCD_REMAP && (G & 7) == 0) item = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
 
     // ---- staging map of the item being PREFETCHED (chunk-invariant) ---------------------------
     // X: unit u = it*256 + tid -> pixel q = u>>3, 16-B piece j = u&7 of that pixel's 128-B channel
@@ -287,7 +290,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_ring_kernel(ConvParams 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nchunks = p.Cinp >> 5;
     const int pix_stride = p.Cinp * 4;
+    // blocks b and b+8 share an XCD (round-robin dispatch): give every XCD a contiguous run of items, so
+    // the cout-tile siblings that re-read one input tile (and neighbouring tiles' halos) hit the same L2
     int b = blockIdx.x;
+    if (ESA_XCD_REMAP && (gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
     const int ct = b % ctiles; b /= ctiles;
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
