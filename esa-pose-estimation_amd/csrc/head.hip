@@ -134,12 +134,215 @@ int launch_final_t(const FinalParams& p, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Matrix-core version of the same op.  The contraction index is (tap, channel) with the K+cin concat
+// channels padded to CG groups of 8: K-slot group G = tap*CG + cg, four groups per 32-wide MFMA chunk.
+// The workgroup builds the halo'd 18x18 concat tile ONCE in LDS as split-bf16 operand planes
+// [part][cg][pixel][16 B] (bilinear taps + raw input, then hi/lo split), and every tap is just another
+// LDS address of that tile (no im2col).  A = tile fragments (rows = 16 pixels of an output row),
+// B = weight fragments (columns = output channels), so D[pixel][cout] leaves 4 consecutive pixels of
+// one heat-map in a lane: 16-byte stores into the f32 NCHW output.
+constexpr int MTH = 16, MTW = 16;                 // output tile
+constexpr int MIH = MTH + 2, MIW = MTW + 2;
+constexpr int MPLANE = ((MIH * MIW * 16 + 255) / 256) * 256;       // 5376 B, multiple of 256 B (bank-congruent planes)
+
+template <int CG, int M>
+__global__ __launch_bounds__(256, 2) void final_mfma_kernel(FinalParams p, const uint4* __restrict__ wpk, int tiles_x,
+                                                           int tiles_y) {
+    constexpr int NG = 9 * CG;                    // K-slot groups carrying weights
+    constexpr int NCH = (NG + 3) / 4;             // 32-wide chunks
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const tile = smem;                      // [part][cg][pixel][16 B]
+    char* const wl = smem + 2 * CG * MPLANE;      // [m][chunk][part][lane][16 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int oy0 = ty * MTH, ox0 = tx * MTW;
+
+    // ---- weights -> LDS ------------------------------------------------------------------------------
+    for (int u = tid; u < M * NCH * 2 * 64; u += 256) *reinterpret_cast<uint4*>(wl + u * 16) = wpk[u];
+
+    // ---- concat tile -> LDS operand planes: unit = (pixel, channel group) --------------------------
+    for (int u = tid; u < MIH * MIW * CG; u += 256) {
+        const int cg = u % CG;
+        const int q = u / CG;
+        const int py = q / MIW, px = q - py * MIW;
+        const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+            if (cg * 8 < p.K) {                   // up-sampled keypoint channels of this group
+                const LerpT ly = lerp_ac_true(gy, p.h, p.H), lx = lerp_ac_true(gx, p.wd, p.W);
+                const size_t r0 = ((size_t)n * p.h + ly.i0) * p.wd, r1 = ((size_t)n * p.h + ly.i1) * p.wd;
+                const size_t ps = (size_t)p.Cp * 4;
+                float v00[8], v01[8], v10[8], v11[8];
+                const char* a;
+                a = p.h3 + (r0 + lx.i0) * ps + cg * 32;
+                join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v00);
+                a = p.h3 + (r0 + lx.i1) * ps + cg * 32;
+                join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v01);
+                a = p.h3 + (r1 + lx.i0) * ps + cg * 32;
+                join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v10);
+                a = p.h3 + (r1 + lx.i1) * ps + cg * 32;
+                join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v11);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (cg * 8 + i < p.K)
+                        v[i] = ly.l0 * (lx.l0 * v00[i] + lx.l1 * v01[i]) + ly.l1 * (lx.l0 * v10[i] + lx.l1 * v11[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {         // raw input channels that fall into this group
+                const int ci = cg * 8 + i - p.K;
+                if (ci >= 0 && ci < p.cin) v[i] = p.x0[(((size_t)n * p.cin + ci) * p.H + gy) * p.W + gx];
+            }
+        }
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        *reinterpret_cast<uint4*>(tile + cg * MPLANE + q * 16) = hi;
+        *reinterpret_cast<uint4*>(tile + (CG + cg) * MPLANE + q * 16) = lo;
+    }
+
+    // per-lane tile offset of K-slot group (chunk, g): plane of its channel group + the tap's pixel shift
+    int offp[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        int G = c * 4 + g;
+        G = G < NG ? G : 0;                       // padded groups have zero weights: any valid address
+        const int tap = G / CG, cg = G - tap * CG;
+        offp[c] = cg * MPLANE + ((tap / 3) * MIW + (tap % 3) + i16) * 16;
+    }
+    __syncthreads();
+
+    // ---- 4 output rows per wave -----------------------------------------------------------------
+    f32x4 acc[M][4];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const float bv = p.bias[m * 16 + i16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{bv, bv, bv, bv};
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        bf16x8 wh[M], wlo[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            wh[m] = *reinterpret_cast<const bf16x8*>(wl + (((m * NCH + c) * 2 + 0) * 64 + lane) * 16);
+            wlo[m] = *reinterpret_cast<const bf16x8*>(wl + (((m * NCH + c) * 2 + 1) * 64 + lane) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const char* a = tile + offp[c] + ((wave * 4 + t) * MIW) * 16;
+            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(a);
+            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(a + CG * MPLANE);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh[m], acc[m][t], 0, 0, 0);
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wlo[m], acc[m][t], 0, 0, 0);
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh[m], acc[m][t], 0, 0, 0);
+            }
+        }
+    }
+    // D[pixel][cout]: lane = cout i16 (+16 m), registers = pixels ox0 + 4g .. +3 of row oy
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int k = m * 16 + i16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int oy = oy0 + wave * 4 + t, ox = ox0 + g * 4;
+            if (k < p.K && oy < p.H && ox < p.W) {
+                float* o = p.out + (((size_t)n * p.K + k) * p.H + oy) * p.W + ox;
+                if (ox + 3 < p.W && (p.W & 3) == 0) *reinterpret_cast<f32x4*>(o) = acc[m][t];
+                else
+                    for (int r = 0; r < 4 && ox + r < p.W; ++r) o[r] = acc[m][t][r];
+            }
+        }
+    }
+}
+
+template <int CG, int M>
+int launch_final_mfma_t(const FinalParams& p, hipStream_t stream) {
+    constexpr int NCH = (9 * CG + 3) / 4;
+    const int tiles_x = (p.W + MTW - 1) / MTW, tiles_y = (p.H + MTH - 1) / MTH;
+    const long long nblk = (long long)p.N * tiles_x * tiles_y;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const int lds = 2 * CG * MPLANE + M * NCH * 2048;
+    auto kern = final_mfma_kernel<CG, M>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, p, p.wpk, tiles_x, tiles_y);
+    return (int)hipGetLastError();
+}
+
+static inline uint16_t fb16(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float fb16f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
 }  // namespace
 
 // padded output-channel count the weights/bias of the final conv must be packed with
 int final_kt(int K) { return K <= 11 ? 11 : (K <= 16 ? 16 : (K <= 32 ? 32 : -1)); }
 
+// MFMA path: channel groups CG = ceil((K+cin)/8) in {2..5}, M = ceil(K/16) in {1,2}
+bool final_mfma_supported(int K, int cin) {
+    const int cg = (K + cin + 7) / 8;
+    return K >= 1 && K <= 32 && cg >= 2 && cg <= 5;
+}
+size_t final_mfma_bytes(int K, int cin) {
+    const int cg = (K + cin + 7) / 8, m = (K + 15) / 16, nch = (9 * cg + 3) / 4;
+    return (size_t)m * nch * 2048;
+}
+// w: [K][K+cin][3][3] (reference layout) -> [m][chunk][hi|lo][lane][8]: lane (cout = m*16 + (l&15), g = l>>4),
+// element j <-> K-slot group G = chunk*4 + g = tap*CG + cg, channel cg*8 + j
+void pack_final_mfma(const float* w, int K, int cin, void* dst) {
+    uint16_t* d = static_cast<uint16_t*>(dst);
+    const int ct = K + cin, cg_n = (ct + 7) / 8, m_n = (K + 15) / 16, nch = (9 * cg_n + 3) / 4;
+    for (int m = 0; m < m_n; ++m)
+        for (int c = 0; c < nch; ++c)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = m * 16 + (l & 15), G = c * 4 + (l >> 4);
+                    float v = 0.f;
+                    if (G < 9 * cg_n) {
+                        const int tap = G / cg_n, ch = (G % cg_n) * 8 + j;
+                        if (co < K && ch < ct) v = w[((size_t)co * ct + ch) * 9 + tap];
+                    }
+                    const uint16_t hi = fb16(v), lo = fb16(v - fb16f(hi));
+                    const size_t base = (((size_t)m * nch + c) * 2) * 512;
+                    d[base + l * 8 + j] = hi;
+                    d[base + 512 + l * 8 + j] = lo;
+                }
+}
+
 int launch_final(const FinalParams& p, hipStream_t stream) {
+    if (p.wpk && final_mfma_supported(p.K, p.cin)) {
+        const int cg = (p.K + p.cin + 7) / 8, m = (p.K + 15) / 16;
+        switch (cg * 10 + m) {
+            case 21: return launch_final_mfma_t<2, 1>(p, stream);
+            case 31: return launch_final_mfma_t<3, 1>(p, stream);
+            case 32: return launch_final_mfma_t<3, 2>(p, stream);
+            case 42: return launch_final_mfma_t<4, 2>(p, stream);
+            case 52: return launch_final_mfma_t<5, 2>(p, stream);
+        }
+    }
     switch (final_kt(p.K)) {
         case 11: return launch_final_t<11>(p, stream);
         case 16: return launch_final_t<16>(p, stream);

@@ -21,7 +21,7 @@ namespace esa {
 namespace {
 
 template <int NCH>
-__global__ __launch_bounds__(256, 2) void head_t_kernel(HeadTParams p, int tiles_per_row, long long ntiles) {
+__global__ __launch_bounds__(256, 2) void head_t_kernel(HeadTParams p, int tiles_per_row, long long ntiles, int csplit) {
     constexpr int WFR = 4 * NCH;                   // 1-KB weight fragments per 32-channel chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,6 +33,8 @@ __global__ __launch_bounds__(256, 2) void head_t_kernel(HeadTParams p, int tiles
     const int col = k * 16 - HT_PAD + i;
     const bool valid = live && col >= 0 && col < p.w;
     const int nchunks = p.Ctp >> 5;
+    // blockIdx.y splits the output-channel chunks (small grids: more workgroups, each re-loading its x fragments)
+    const int c_begin = (int)blockIdx.y * csplit, c_end = min(c_begin + csplit, nchunks);
 
     bf16x8 xh[NCH], xl[NCH];
 #pragma unroll
@@ -60,13 +62,13 @@ __global__ __launch_bounds__(256, 2) void head_t_kernel(HeadTParams p, int tiles
         _Pragma("unroll") for (int it = 0; it < NCH; ++it)                                    \
             *reinterpret_cast<u32x4*>(smem + (BUF) * (WFR * 1024) + (it * 256 + tid) * 16) = wreg[it]; \
     }
-    HT_PREFETCH(0)
+    HT_PREFETCH(c_begin)
     HT_COMMIT(0)
     __syncthreads();
     char* trow = p.t + (size_t)row * nchunks * 64 * (size_t)(p.XP * 2) + (size_t)(k * 16 + g * 4) * 2;
-    for (int cc = 0; cc < nchunks; ++cc) {
-        const int buf = cc & 1;
-        if (cc + 1 < nchunks) HT_PREFETCH(cc + 1)
+    for (int cc = c_begin; cc < c_end; ++cc) {
+        const int buf = (cc - c_begin) & 1;
+        if (cc + 1 < c_end) HT_PREFETCH(cc + 1)
         const char* wb = smem + buf * (WFR * 1024) + lane * 16;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void head_t_kernel(HeadTParams p, int tiles
                 *reinterpret_cast<uint2*>(o + (size_t)32 * p.XP * 2) = lo;
             }
         }
-        if (cc + 1 < nchunks) {
+        if (cc + 1 < c_end) {
             HT_COMMIT(buf ^ 1)
             __syncthreads();
         }
@@ -112,7 +114,13 @@ int launch_head_t_n(const HeadTParams& p, hipStream_t stream) {
     const long long ntiles = (long long)p.N * p.h * tiles_per_row;
     const long long nblk = (ntiles + 3) / 4;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, p, tiles_per_row, ntiles);
+    // aim for >= 4 workgroups per CU: split the chunk loop over blockIdx.y when the pixel grid is small
+    const int nchunks = p.Ctp >> 5;
+    int parts = 1;
+    while (nblk * parts < 1024 && parts * 2 <= nchunks) parts *= 2;
+    const int csplit = (nchunks + parts - 1) / parts;
+    const int ny = (nchunks + csplit - 1) / csplit;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)ny), dim3(256), lds, stream, p, tiles_per_row, ntiles, csplit);
     return (int)hipGetLastError();
 }
 

@@ -76,11 +76,15 @@ struct FinalParams {
     const float* x0;    // f32 [N][cin][H][W]
     float* out;         // f32 [N][K][H][W]
     const float* w;     // f32 [K+cin][9][K]   (repacked: output channel innermost)
-    const float* bias;  // f32 [K]
+    const float* bias;  // f32 [K] (padded with zeros to 32)
+    const uint4* wpk;   // MFMA path: split-bf16 fragments (pack_final_mfma), or nullptr -> VALU kernel
     int N, H, W, h, wd; // h,wd = resolution of h3
     int K, cin, Cp;
 };
 int launch_final(const FinalParams& p, hipStream_t stream);
+bool final_mfma_supported(int K, int cin);
+size_t final_mfma_bytes(int K, int cin);
+void pack_final_mfma(const float* w, int K, int cin, void* dst);
 
 // ---- fused head: W0*x0 + sum up(t_b) + bias, ReLU, W3*(.) + bias, ReLU (head_fused.hip) ----------
 struct HeadParams {

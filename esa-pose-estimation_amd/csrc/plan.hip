@@ -131,6 +131,7 @@ struct esahrnet_ctx {
     std::vector<Op> ops;
     int spec_stem = -1, spec_final = -1;
     float *stem_w = nullptr, *stem_b = nullptr, *final_w = nullptr, *final_b = nullptr;
+    void* final_wpk = nullptr;  // output_layer weights as MFMA fragments (head.hip, final_mfma_kernel)
     int spec_l0 = -1, spec_l3 = -1, head_c0 = 0;     // fused head (OP_HEAD)
     void *head_w0 = nullptr, *head_w3 = nullptr;
     float *head_b0 = nullptr, *head_b3 = nullptr;
@@ -467,6 +468,7 @@ int build_plan(esahrnet_ctx& c) {
             off += pre[b];
         }
         o.out = B.tensor(K, 1, "head3");
+        c.tensors[o.out].Cp = (K + 15) & ~15;     // read only by head.hip: 16-channel pitch halves its traffic for K <= 16
         const int idx = (int)c.ops.size();
         c.tensors[o.out].def = idx;
         B.use(o.in, idx);
@@ -660,7 +662,7 @@ void free_weights(esahrnet_ctx& c) {
     }
     for (float** p : {&c.stem_w, &c.stem_b, &c.final_w, &c.final_b, &c.head_b0, &c.head_b3})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
-    for (void** p : {&c.head_w0, &c.head_w3})
+    for (void** p : {&c.head_w0, &c.head_w3, &c.final_wpk})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (AuxSpec& a : c.aux) if (a.dev) { (void)hipFree(a.dev); a.dev = nullptr; }
     for (float** p : {&c.stemraw_w, &c.stemraw_b}) if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -814,7 +816,12 @@ int esahrnet_commit(esahrnet_handle h) {
     if (h->cfg.variant == 0) {   // final: [K+cin][9][KT]
         const ConvSpec& s = h->specs[h->spec_final];
         const int kt = esa::final_kt(s.cout);
-        std::vector<float> w((size_t)s.cin * 9 * kt, 0.f), b(kt, 0.f);
+        std::vector<float> w((size_t)s.cin * 9 * kt, 0.f), b(std::max(kt, 32), 0.f);
+        if (esa::final_mfma_supported(s.cout, s.cin - s.cout) && !getenv("ESAHRNET_FINAL_VALU")) {
+            packed.assign(esa::final_mfma_bytes(s.cout, s.cin - s.cout), 0);
+            esa::pack_final_mfma(s.w.data(), s.cout, s.cin - s.cout, packed.data());
+            if (upload(packed, &h->final_wpk)) return 1;
+        }
         for (int co = 0; co < s.cout; ++co) {
             b[co] = s.b[co];
             for (int ci = 0; ci < s.cin; ++ci)
@@ -1101,7 +1108,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 const Tensor& ti = h->tensors[o.in];
                 esa::FinalParams p{};
                 p.h3 = T(o.in); p.x0 = static_cast<const float*>(x_dev); p.out = static_cast<float*>(heat_dev);
-                p.w = h->final_w; p.bias = h->final_b;
+                p.w = h->final_w; p.bias = h->final_b; p.wpk = static_cast<const uint4*>(h->final_wpk);
                 p.N = n; p.H = height; p.W = width; p.h = sp.lh[ti.level]; p.wd = sp.lw[ti.level];
                 p.K = h->cfg.num_keypoints; p.cin = h->cfg.cin; p.Cp = ti.Cp;
                 rc = esa::launch_final(p, stream);
