@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void final_mfma_kernel(FinalParams p, const
     char* const wl = smem + 2 * CG * MPLANE;      // [m][chunk][part][lane][16 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    int b = blockIdx.x;
+    int b = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
     const int n = b / tiles_y;

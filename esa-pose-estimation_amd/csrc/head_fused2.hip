@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NW * 64, 4) void head_fused2_kernel(Head2Params p, 
     char* const w1b = w03b + 2 * W03S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int px = lane & 15, q = lane >> 4;
-    int b_ = blockIdx.x;
+    int b_ = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = b_ % tiles_x; b_ /= tiles_x;
     const int ty = b_ % tiles_y;
     const int n = b_ / tiles_y;

@@ -10,6 +10,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Workgroups b and b+8 run on the same XCD (round-robin dispatch over the 8 XCDs, each with its own L2).
+// Kernels whose neighbouring tiles share input (halos, interpolation windows, cout-tile siblings) map
+// blockIdx through this so that every XCD owns one contiguous run of tiles and the shared lines are
+// fetched from HBM / Infinity Cache once instead of once per XCD.
+__device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
+    return (nblocks & 7) == 0 ? (b & 7) * (nblocks >> 3) + (b >> 3) : b;
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;

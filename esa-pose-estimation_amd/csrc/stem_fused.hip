@@ -38,7 +38,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void stem_fused_kernel(StemFusedParams
     float* raw = reinterpret_cast<float*>(smem + SC::XBYTES + SC::WBYTES);   // [CIN][RH][RPITCH]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = blockIdx.x;
+    int b = xcd_contiguous(blockIdx.x, gridDim.x);
     const int ct = b % ctiles; b /= ctiles;
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
