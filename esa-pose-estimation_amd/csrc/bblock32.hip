@@ -145,17 +145,15 @@ __global__ __launch_bounds__(BTHREADS, 1) void bblock32_kernel(BlockParams p, in
         // conv1's MFMAs — a full MFMA phase later, so the latency is covered
         const int ox = ox0 + px;
         f32x4 acc2[2][2];
-        uint2 rh[2][2], rl[2][2];
+        uint4 rc[2][2];                        // one 16-byte chunk per lane (sb.h: chunk_to_quad)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 acc2[m][t] = b2v[m];
                 const int oyc = min(oy0 + wave * 2 + t, p.H - 1), oxc = min(ox, p.W - 1);
-                const int co = m * 16 + g * 4;
-                const char* r = p.x + ((size_t)(n * p.H + oyc) * p.W + oxc) * 128 + (co >> 3) * 32 + ((co >> 2) & 1) * 8;
-                rh[m][t] = BB_DO_RES ? *reinterpret_cast<const uint2*>(r) : make_uint2(0, 0);
-                rl[m][t] = BB_DO_RES ? *reinterpret_cast<const uint2*>(r + 16) : make_uint2(0, 0);
+                const char* r = p.x + ((size_t)(n * p.H + oyc) * p.W + oxc) * 128 + chunk_ofs(m * 16 + g * 4, g);
+                rc[m][t] = BB_DO_RES ? *reinterpret_cast<const uint4*>(r) : make_uint4(0, 0, 0, 0);
             }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -191,7 +189,9 @@ __global__ __launch_bounds__(BTHREADS, 1) void bblock32_kernel(BlockParams p, in
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float rv[4];
-                join4(rh[m][t], rl[m][t], rv);
+                uint2 rh, rl;
+                chunk_to_quad(rc[m][t], rh, rl);
+                join4(rh, rl, rv);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc2[m][t][i] += rv[i];
             }
@@ -256,17 +256,14 @@ __global__ __launch_bounds__(BTHREADS, 1) void bblock32_kernel(BlockParams p, in
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int oy = oy0 + wave * 2 + t;
-                if ((BB_DO_STORE || acc2[m][t][0] == 123.456f) && oy < p.H && ox < p.W) {
-                    const int co = m * 16 + g * 4;
-                    char* o = p.y + ((size_t)(n * p.H + oy) * p.W + ox) * 128 + (co >> 3) * 32 + ((co >> 2) & 1) * 8;
-                    float v[4];
+                float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = relu1(acc2[m][t][i]);
-                    uint2 hi, lo;
-                    split4(v, hi, lo);
-                    *reinterpret_cast<uint2*>(o) = hi;
-                    *reinterpret_cast<uint2*>(o + 16) = lo;
-                }
+                for (int i = 0; i < 4; ++i) v[i] = relu1(acc2[m][t][i]);
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                const uint4 ch = quad_to_chunk(hi, lo);            // all lanes; only the store is predicated
+                if ((BB_DO_STORE || acc2[m][t][0] == 123.456f) && oy < p.H && ox < p.W)
+                    *reinterpret_cast<uint4*>(p.y + ((size_t)(n * p.H + oy) * p.W + ox) * 128 + chunk_ofs(m * 16 + g * 4, g)) = ch;
             }
         item = next;
     }

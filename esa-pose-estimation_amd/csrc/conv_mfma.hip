@@ -47,6 +47,12 @@
 #ifndef ESA_DO_STORE
 #define ESA_DO_STORE 1
 #endif
+#ifndef ESA_DO_WDMA
+#define ESA_DO_WDMA 1
+#endif
+#ifndef ESA_DO_RES
+#define ESA_DO_RES 1
+#endif
 #ifndef ESA_XCD_REMAP
 #define ESA_XCD_REMAP 1
 #endif
@@ -163,15 +169,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
         for (int m = 0; m < MT; ++m) {
             const int co = (ct * MT + m) * 16 + g * 4;                 // first of this lane's 4 couts
             const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
-            const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;     // byte offset inside the pixel
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
                 acc[m][t] = bv;
                 const int oy = oy0 + wave * C::NT + t;
-                if (p.res && oy < p.OH && ox < p.OW) {
-                    const size_t o = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + cofs;
-                    const uint2 rh = *reinterpret_cast<const uint2*>(p.res + o);
-                    const uint2 rl = *reinterpret_cast<const uint2*>(p.res + o + 16);
+                if (p.res) {                   // 16-byte chunk per lane, halves swapped into quads (sb.h)
+                    uint4 rc = make_uint4(0, 0, 0, 0);
+                    if (oy < p.OH && ox < p.OW)
+                        rc = *reinterpret_cast<const uint4*>(p.res + ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + chunk_ofs(co, g));
+                    uint2 rh, rl;
+                    chunk_to_quad(rc, rh, rl);
                     float r[4];
                     join4(rh, rl, r);
 #pragma unroll
@@ -236,26 +243,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int co = (ct * MT + m) * 16 + g * 4;
-            const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;
 #pragma unroll
             for (int t = 0; t < C::NT; ++t) {
                 const int oy = oy0 + wave * C::NT + t;
-                if ((ESA_DO_STORE || acc[m][t][0] == 123.456f) && oy < p.OH && ox < p.OW) {
-                    float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
-                    if (p.relu) {
+                const bool inr = (ESA_DO_STORE || acc[m][t][0] == 123.456f) && oy < p.OH && ox < p.OW;
+                float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
+                if (p.relu) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
-                    }
-                    if (p.out_f32) {
-                        const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
-                        *reinterpret_cast<f32x4*>(p.y + of) = f32x4{v[0], v[1], v[2], v[3]};
-                    } else {
-                        const size_t o = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + cofs;
-                        uint2 hi, lo;
-                        split4(v, hi, lo);
-                        *reinterpret_cast<uint2*>(p.y + o) = hi;
-                        *reinterpret_cast<uint2*>(p.y + o + 16) = lo;
-                    }
+                    for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
+                }
+                if (p.out_f32) {
+                    const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
+                    if (inr) *reinterpret_cast<f32x4*>(p.y + of) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    const uint4 ch = quad_to_chunk(hi, lo);        // all lanes; only the store is predicated
+                    if (inr) *reinterpret_cast<uint4*>(p.y + ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + chunk_ofs(co, g)) = ch;
                 }
             }
         }
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_ring_kernel(ConvParams 
     {                                                                                             \
         _Pragma("unroll") for (int it = 0; it < C::XITER; ++it) {                                 \
             uint4 v = make_uint4(0, 0, 0, 0);                                                     \
-            if (xg[it] >= 0) v = *reinterpret_cast<const uint4*>(xn + xg[it] + (CH) * 128);       \
+            if (ESA_DO_XLOAD && xg[it] >= 0) v = *reinterpret_cast<const uint4*>(xn + xg[it] + (CH) * 128); \
             xr[it] = v;                                                                           \
         }                                                                                         \
     }
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_ring_kernel(ConvParams 
     {                                                                                             \
         _Pragma("unroll") for (int it = 0; it < DPW; ++it) {                                      \
             const int f = it * 4 + wave;                                                          \
-            if (f < THIRD_FRAGS) {                                                                \
+            if (ESA_DO_WDMA && f < THIRD_FRAGS) {                                                 \
                 const int mt = f / 6, r6 = f - mt * 6, ky = r6 >> 1, part = r6 & 1;               \
                 const uint4* src = wbase + ((size_t)mt * nchunks + (CH)) * (C::TAPS * 128) +      \
                                    ((ky * 3 + (KX)) * 2 + part) * 64 + lane;                      \
@@ -344,15 +348,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_ring_kernel(ConvParams 
     for (int m = 0; m < MT; ++m) {
         const int co = (ct * MT + m) * 16 + g * 4;
         const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
-        const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
             acc[m][t] = bv;
             const int oy = oy0 + wave * C::NT + t;
-            if (p.res && oy < p.OH && ox < p.OW) {
-                const size_t o = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + cofs;
-                const uint2 rh = *reinterpret_cast<const uint2*>(p.res + o);
-                const uint2 rl = *reinterpret_cast<const uint2*>(p.res + o + 16);
+            if (ESA_DO_RES && p.res) {         // 16-byte chunk per lane, halves swapped into quads (sb.h)
+                uint4 rc = make_uint4(0, 0, 0, 0);
+                if (oy < p.OH && ox < p.OW)
+                    rc = *reinterpret_cast<const uint4*>(p.res + ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + chunk_ofs(co, g));
+                uint2 rh, rl;
+                chunk_to_quad(rc, rh, rl);
                 float r[4];
                 join4(rh, rl, r);
 #pragma unroll
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_ring_kernel(ConvParams 
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int d = i - ky;
-                    if (d >= 0 && d % S == 0 && d / S < C::NT) {
+                    if (ESA_DO_MFMA && d >= 0 && d % S == 0 && d / S < C::NT) {
                         const int t = d / S;
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
@@ -427,26 +432,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_ring_kernel(ConvParams 
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int co = (ct * MT + m) * 16 + g * 4;
-        const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
             const int oy = oy0 + wave * C::NT + t;
-            if (oy < p.OH && ox < p.OW) {
-                float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
-                if (p.relu) {
+            const bool inr = (ESA_DO_STORE || acc[m][t][0] == 123.456f) && oy < p.OH && ox < p.OW;
+            float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
+            if (p.relu) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
-                }
-                if (p.out_f32) {
-                    const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
-                    *reinterpret_cast<f32x4*>(p.y + of) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    const size_t o = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + cofs;
-                    uint2 hi, lo;
-                    split4(v, hi, lo);
-                    *reinterpret_cast<uint2*>(p.y + o) = hi;
-                    *reinterpret_cast<uint2*>(p.y + o + 16) = lo;
-                }
+                for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
+            }
+            if (p.out_f32) {
+                const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
+                if (inr) *reinterpret_cast<f32x4*>(p.y + of) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                const uint4 ch = quad_to_chunk(hi, lo);            // all lanes; only the store is predicated
+                if (inr) *reinterpret_cast<uint4*>(p.y + ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + chunk_ofs(co, g)) = ch;
             }
         }
     }

@@ -67,6 +67,26 @@ __device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
     split2(v[2], v[3], hi.y, lo.y);
 }
 
+// Accumulator quad <-> SB memory with 16-byte accesses.  An MFMA D tile leaves, in the lanes of 16-lane
+// row q, 4 consecutive channels (hi 8 B, lo 8 B) of one pixel; rows q and q^1 together hold one
+// 8-channel SB group [hi 16 B | lo 16 B].  v_permlane16_swap exchanges the halves so that the even
+// row owns the whole lo chunk and the odd row the whole hi chunk: one 16-byte access per lane instead
+// of two 8-byte ones (the 8-byte pattern ran the epilogue stores at ~3 TB/s).  Both helpers must be
+// executed by all 64 lanes (predicate the memory access, not the swap).
+__device__ __forceinline__ uint4 quad_to_chunk(uint2 hi, uint2 lo) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
+    return make_uint4(r0[0], r1[0], r0[1], r1[1]);      // even rows: lo chunk, odd rows: hi chunk
+}
+__device__ __forceinline__ void chunk_to_quad(uint4 c, uint2& hi, uint2& lo) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(c.x, c.z, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(c.y, c.w, false, false);
+    lo = make_uint2(r0[0], r1[0]);
+    hi = make_uint2(r0[1], r1[1]);
+}
+// byte offset inside the pixel of the chunk owned by a lane of row q for the quad of channels co..co+3
+__device__ __forceinline__ int chunk_ofs(int co, int q) { return (co >> 3) * 32 + ((q & 1) ? 0 : 16); }
+
 __device__ __forceinline__ void join4(uint2 hi, uint2 lo, float v[4]) {
     v[0] = bf16_bits_to_f32(hi.x & 0xffffu) + bf16_bits_to_f32(lo.x & 0xffffu);
     v[1] = bf16_bits_to_f32(hi.x >> 16) + bf16_bits_to_f32(lo.x >> 16);

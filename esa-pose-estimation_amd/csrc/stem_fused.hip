@@ -175,21 +175,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void stem_fused_kernel(StemFusedParams
 #undef SF_DMA_W
     // ---- epilogue: ReLU, split, store ---------------------------------------------------------------
     const int ox = ox0 + (lane & 15), oy = oy0 + wave;
-    if (oy < p.OH && ox < p.OW) {
+    const bool inr = oy < p.OH && ox < p.OW;
 #pragma unroll
-        for (int km = 0; km < CT * SF_MT; ++km) {
-            const int k = km / SF_MT, m = km % SF_MT;
-            const int co = ((ct * CT + k) * SF_MT + m) * 16 + g * 4;
-            const int cofs = (co >> 3) * 32 + ((co >> 2) & 1) * 8;
-            float v[4];
+    for (int km = 0; km < CT * SF_MT; ++km) {
+        const int k = km / SF_MT, m = km % SF_MT;
+        const int co = ((ct * CT + k) * SF_MT + m) * 16 + g * 4;
+        float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = relu1(acc[k][m][i]);
-            uint2 hi, lo;
-            split4(v, hi, lo);
-            char* o = p.y + ((size_t)(n * p.OH + oy) * p.OW + ox) * (size_t)(p.Coutp * 4) + cofs;
-            *reinterpret_cast<uint2*>(o) = hi;
-            *reinterpret_cast<uint2*>(o + 16) = lo;
-        }
+        for (int i = 0; i < 4; ++i) v[i] = relu1(acc[k][m][i]);
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        const uint4 ch = quad_to_chunk(hi, lo);                    // all lanes; only the store is predicated
+        if (inr) *reinterpret_cast<uint4*>(p.y + ((size_t)(n * p.OH + oy) * p.OW + ox) * (size_t)(p.Coutp * 4) + chunk_ofs(co, g)) = ch;
     }
 }
 
