@@ -39,44 +39,68 @@ __device__ __forceinline__ void load_group(const char* base, size_t pix, int Cp,
     join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
 }
 
-__global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, long long total) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+// lerp with the scale in/out handed over by the host (same f32 quotient as ATen computes)
+__device__ __forceinline__ Lerp lerp_scaled(int dst, int in, float scale) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    Lerp r;
+    r.i0 = min((int)src, in - 1);
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+struct FuseScales {
+    float sy[4], sx[4];
+};
+
+// One workgroup row = one output row (blockIdx.y = n*H + y): the row decomposition and the vertical
+// interpolation are wave-uniform, all per-lane index math is 32-bit.  NS same-resolution terms come
+// first, then NU lower-resolution terms (the host orders them); both counts are compile-time.
+template <int NS, int NU>
+__global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) {
     const int G = p.Cp >> 3;
-    const int c8 = (int)(idx % G);
-    long long pix = idx / G;
-    const int x = (int)(pix % p.W);
-    long long row = pix / p.W;
-    const int y = (int)(row % p.H);
-    const int n = (int)(row / p.H);
+    const unsigned u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= (unsigned)(p.W * G)) return;
+    const int x = (int)(u / (unsigned)G);
+    const int c8 = (int)(u - (unsigned)x * (unsigned)G);
+    const int row = blockIdx.y;                   // n*H + y
+    const int n = row / p.H, y = row - n * p.H;
+    const int pixb = p.Cp * 4;
 
     float acc[8];
+    if (NS > 0) {
+        const char* a = p.x[0] + ((size_t)row * p.W + x) * (size_t)pixb + c8 * 32;
+        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), acc);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int t = 0; t < p.nterms; ++t) {
-        const int h = p.h[t], w = p.w[t];
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    }
+#pragma unroll
+    for (int t = 1; t < NS; ++t) {
         float v[8];
-        if (h == p.H && w == p.W) {
-            load_group(p.x[t], (size_t)pix, p.Cp, c8, v);
-        } else {
-            const Lerp ly = lerp_ac_false(y, h, p.H), lx = lerp_ac_false(x, w, p.W);
-            const size_t r0 = ((size_t)n * h + ly.i0) * w, r1 = ((size_t)n * h + ly.i1) * w;
-            float v00[8], v01[8], v10[8], v11[8];
-            load_group(p.x[t], r0 + lx.i0, p.Cp, c8, v00);
-            load_group(p.x[t], r0 + lx.i1, p.Cp, c8, v01);
-            load_group(p.x[t], r1 + lx.i0, p.Cp, c8, v10);
-            load_group(p.x[t], r1 + lx.i1, p.Cp, c8, v11);
+        const char* a = p.x[t] + ((size_t)row * p.W + x) * (size_t)pixb + c8 * 32;
+        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                v[i] = ly.l0 * (lx.l0 * v00[i] + lx.l1 * v01[i]) + ly.l1 * (lx.l0 * v10[i] + lx.l1 * v11[i]);
-        }
-        if (t == 0) {
+        for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = v[i];
-        } else {
+    for (int k = 0; k < NU; ++k) {
+        const int t = NS + k;
+        const int h = p.h[t], w = p.w[t];
+        const Lerp ly = lerp_scaled(y, h, fs.sy[t]), lx = lerp_scaled(x, w, fs.sx[t]);
+        const char* r0 = p.x[t] + ((size_t)n * h + ly.i0) * w * (size_t)pixb + c8 * 32;
+        const char* r1 = p.x[t] + ((size_t)n * h + ly.i1) * w * (size_t)pixb + c8 * 32;
+        const int o0 = lx.i0 * pixb, o1 = lx.i1 * pixb;
+        float v00[8], v01[8], v10[8], v11[8];
+        join8(*reinterpret_cast<const uint4*>(r0 + o0), *reinterpret_cast<const uint4*>(r0 + o0 + 16), v00);
+        join8(*reinterpret_cast<const uint4*>(r0 + o1), *reinterpret_cast<const uint4*>(r0 + o1 + 16), v01);
+        join8(*reinterpret_cast<const uint4*>(r1 + o0), *reinterpret_cast<const uint4*>(r1 + o0 + 16), v10);
+        join8(*reinterpret_cast<const uint4*>(r1 + o1), *reinterpret_cast<const uint4*>(r1 + o1 + 16), v11);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += v[i];
-        }
+        for (int i = 0; i < 8; ++i)
+            acc[i] += ly.l0 * (lx.l0 * v00[i] + lx.l1 * v01[i]) + ly.l1 * (lx.l0 * v10[i] + lx.l1 * v11[i]);
     }
     if (p.relu) {
 #pragma unroll
@@ -84,20 +108,56 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, long long total
     }
     uint4 hi, lo;
     split8(acc, hi, lo);
-    char* o = p.y + (size_t)pix * (size_t)(p.Cp * 4) + c8 * 32;
+    char* o = p.y + ((size_t)row * p.W + x) * (size_t)pixb + c8 * 32;
     *reinterpret_cast<uint4*>(o) = hi;
     *reinterpret_cast<uint4*>(o + 16) = lo;
 }
 
+template <int NS, int NU>
+int launch_fuse_t(const FuseParams& p, const FuseScales& fs, hipStream_t stream) {
+    const long long per_row = (long long)p.W * (p.Cp >> 3);
+    const long long rows = (long long)p.N * p.H;
+    if (per_row <= 0 || rows <= 0 || rows > 0x7fffffffLL || per_row > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((fuse_kernel<NS, NU>), dim3((unsigned)((per_row + 255) / 256), (unsigned)rows), dim3(256), 0, stream, p, fs);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
-int launch_fuse(const FuseParams& p, hipStream_t stream) {
-    if ((p.Cp & 7) || p.nterms < 1 || p.nterms > 4) return (int)hipErrorInvalidValue;
-    const long long total = (long long)p.N * p.H * p.W * (p.Cp >> 3);
-    const long long nblk = (total + 255) / 256;
-    if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(fuse_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, p, total);
-    return (int)hipGetLastError();
+int launch_fuse(const FuseParams& p_in, hipStream_t stream) {
+    if ((p_in.Cp & 7) || p_in.nterms < 1 || p_in.nterms > 4) return (int)hipErrorInvalidValue;
+    // same-resolution terms first (the sum is re-associated; every term is an exact f32 value of SB data)
+    FuseParams p = p_in;
+    FuseScales fs{};
+    int ns = 0, k = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int t = 0; t < p_in.nterms; ++t) {
+            const bool same = p_in.h[t] == p_in.H && p_in.w[t] == p_in.W;
+            if (same != (pass == 0)) continue;
+            p.x[k] = p_in.x[t]; p.h[k] = p_in.h[t]; p.w[k] = p_in.w[t];
+            fs.sy[k] = (float)p_in.h[t] / (float)p_in.H;
+            fs.sx[k] = (float)p_in.w[t] / (float)p_in.W;
+            ++k;
+            if (same) ++ns;
+        }
+    const int nu = p.nterms - ns;
+    switch (ns * 10 + nu) {
+        case 1: return launch_fuse_t<0, 1>(p, fs, stream);
+        case 2: return launch_fuse_t<0, 2>(p, fs, stream);
+        case 3: return launch_fuse_t<0, 3>(p, fs, stream);
+        case 4: return launch_fuse_t<0, 4>(p, fs, stream);
+        case 10: return launch_fuse_t<1, 0>(p, fs, stream);
+        case 11: return launch_fuse_t<1, 1>(p, fs, stream);
+        case 12: return launch_fuse_t<1, 2>(p, fs, stream);
+        case 13: return launch_fuse_t<1, 3>(p, fs, stream);
+        case 20: return launch_fuse_t<2, 0>(p, fs, stream);
+        case 21: return launch_fuse_t<2, 1>(p, fs, stream);
+        case 22: return launch_fuse_t<2, 2>(p, fs, stream);
+        case 30: return launch_fuse_t<3, 0>(p, fs, stream);
+        case 31: return launch_fuse_t<3, 1>(p, fs, stream);
+        case 40: return launch_fuse_t<4, 0>(p, fs, stream);
+    }
+    return (int)hipErrorInvalidValue;
 }
 
 }  // namespace esa

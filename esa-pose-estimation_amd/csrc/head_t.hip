@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void head_t_kernel(HeadTParams p, int tiles
     HT_PREFETCH(c_begin)
     HT_COMMIT(0)
     __syncthreads();
-    char* trow = p.t + (size_t)row * nchunks * 64 * (size_t)(p.XP * 2) + (size_t)(k * 16 + g * 4) * 2;
+    char* trow = p.t + (size_t)row * nchunks * 64 * (size_t)(p.XP * 2) + (size_t)(k * 16 + (g >> 1) * 8) * 2;
     for (int cc = c_begin; cc < c_end; ++cc) {
         const int buf = (cc - c_begin) & 1;
         if (cc + 1 < c_end) HT_PREFETCH(cc + 1)
@@ -81,13 +81,14 @@ __global__ __launch_bounds__(256, 2) void head_t_kernel(HeadTParams p, int tiles
                 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[c], wl, d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[c], wh, d, 0, 0, 0);
             }
-            if (live) {
+            {   // rows g, g^1 of the D tile hold 8 consecutive pixels of a channel: swap halves so that the
+                // odd row stores the hi part and the even row the lo part, 16 bytes each (sb.h)
                 const float v[4] = {d[0], d[1], d[2], d[3]};
                 uint2 hi, lo;
                 split4(v, hi, lo);
-                char* o = trow + ((size_t)(cc * 2) * 32 + m * 16 + i) * (size_t)(p.XP * 2);
-                *reinterpret_cast<uint2*>(o) = hi;
-                *reinterpret_cast<uint2*>(o + (size_t)32 * p.XP * 2) = lo;
+                const uint4 ch = quad_to_chunk(hi, lo);
+                char* o = trow + ((size_t)(cc * 2 + ((g & 1) ? 0 : 1)) * 32 + m * 16 + i) * (size_t)(p.XP * 2);
+                if (live) *reinterpret_cast<uint4*>(o) = ch;
             }
         }
         if (cc + 1 < c_end) {
