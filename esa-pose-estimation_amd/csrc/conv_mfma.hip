@@ -512,7 +512,10 @@ int launch_tp(const ConvParams& p, hipStream_t stream) {
 
 template <int KS, int S, int TH, int MT>
 int launch_t(const ConvParams& p, hipStream_t stream) {
-    if (KS == 3 && p.Cinp == 32) return launch_tp<KS, S, TH, MT, true>(p, stream);
+#ifndef ESA_PERSIST_S1
+#define ESA_PERSIST_S1 1
+#endif
+    if (KS == 3 && p.Cinp == 32 && (S == 2 || ESA_PERSIST_S1)) return launch_tp<KS, S, TH, MT, true>(p, stream);
 #if ESA_CONV_RING
     if constexpr (KS == 3) {
         if (p.Cinp > 32) return launch_ring<S, TH, MT>(p, stream);
