@@ -146,6 +146,42 @@ def test_unfused_plan_matches_reference_golden(env, golden_dir, tag, monkeypatch
     assert err <= GUARD, err
 
 
+@pytest.mark.parametrize("v1", [False, True])
+def test_both_head_generations_match_reference_golden(env, golden_dir, monkeypatch, v1):
+    """The plan carries two heads and picks per input shape: head_fused2 (+ head_t; interpolation on the
+    matrix cores) where its window geometry holds, head_fused otherwise; ESAHRNET_HEAD_V1=1 forces the
+    first generation.  Both must reproduce the reference, and the op list must say which one ran."""
+    if v1:
+        monkeypatch.setenv("ESAHRNET_HEAD_V1", "1")
+    g = np.load(os.path.join(golden_dir, "w32_hrnet2_128.npz"), allow_pickle=False)
+    net, sd = _build(env, "seg_hrnet2", tuple(int(v) for v in g["widths"]), int(g["seed"]))
+    x = env["synth"].make_crops(int(g["n"]), 1, int(g["hw"]), int(g["hw"]), seed=int(g["seed"]))
+    with torch.no_grad():
+        y, ops = net.forward_timed(x.cuda())
+    kernels = [o["kernel"] for o in ops]
+    assert ("head_fused" in kernels) == v1 and ("head_fused2" in kernels) == (not v1)
+    assert ("head_t" in kernels) == (not v1)
+    assert all(k for k in kernels)                      # unused alternatives are not listed
+    s = int(g["subsample"]) if "subsample" in g.files else 1
+    err = np.abs(y.cpu().numpy()[:, :, ::s, ::s] - g["out"]).max()
+    assert err <= GUARD, err
+
+
+def test_odd_geometry_head_carries_lo_weights(env):
+    """18x34 crops: branch grids 9x17 / 5x9 / 3x5 / 2x3 are not 2x/4x/8x of each other, so the
+    interpolation weights are not bf16 numbers: whichever head the geometry check picks (head_fused2 with
+    the lo part of U, or head_fused) must still agree with the oracle."""
+    net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 6)
+    x = env["synth"].make_crops(2, 1, 18, 34, seed=6)
+    with torch.no_grad():
+        ref = env["hrnet_ref"].forward(sd, env["hrnet_ref"].default_cfg(1, 11), x)
+        y, ops = net.forward_timed(x.cuda())
+    kernels = {o["kernel"] for o in ops}
+    assert "head_fused" in kernels or "head_fused2" in kernels
+    print("18x34 head:", sorted(k for k in kernels if k.startswith("head")))
+    assert (y.cpu() - ref).abs().max().item() <= GUARD
+
+
 def test_multistream_executor_matches_single_stream(env, monkeypatch):
     """ESAHRNET_STREAMS=4 runs independent branch chains on side streams ordered by per-op events
     (RAW + buffer-recycling WAR/WAW dependencies).  Must be bit-identical to the single-stream run."""
