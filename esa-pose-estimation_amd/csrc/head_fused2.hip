@@ -72,7 +72,8 @@ __device__ __host__ inline Lerp2 lerp2(int dst, int in, int out) {     // ATen a
 }
 
 template <int NW, int NCH0, int NCH1, int M3, bool ULO>
-__global__ __launch_bounds__(NW * 64, 4) void head_fused2_kernel(Head2Params p, int tiles_x, int tiles_y) {
+// (the wide variants need > 80 KB of LDS, i.e. one workgroup per CU anyway: let them have 256 VGPRs)
+__global__ __launch_bounds__(NW * 64, (NCH0 > 1 || NCH1 > 2) ? 2 : 4) void head_fused2_kernel(Head2Params p, int tiles_x, int tiles_y) {
     constexpr int H2THREADS = NW * 64;
     constexpr int R1 = rows1(NW), R2 = rows2(NW), R3 = rows3(NW);
     constexpr int T1OFF = 0, T2OFF = R1 * 2 * 1024, T3OFF = T2OFF + R2 * 1024, TBUF = T3OFF + R3 * 1024;

@@ -3,8 +3,8 @@
 // Replaces (reference): the caller's two-stage torch.max + >=150 blocking .item() reads per
 // image and the K x H x W device-to-host copy (demo.py:172-185, val.py:151-166), then
 // inference.get_final -> my_taylor on the host (inference.py:136-152, 75-94).  One workgroup
-// per (n,k) plane: every lane keeps (value, first index) over a strided 16-B sweep, a 64-lane
-// DPP/shuffle reduction and one LDS step across the 4 waves pick the first row-major maximum
+// (16 waves) per (n,k) plane: every lane keeps (value, first index) over a strided 16-B sweep, a 64-lane
+// DPP/shuffle reduction and one LDS step across the waves pick the first row-major maximum
 // (== np.argmax / two-stage torch.max tie-break), then one lane evaluates the 9-tap
 // log-quadratic offset in f64 exactly as the reference's Python floats do.
 // NaN policy: comparisons with NaN are false, i.e. NaNs are skipped (the reference would
@@ -18,9 +18,11 @@ __device__ __forceinline__ void take(float v, int i, float& bv, int& bi) {
     if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
 }
 
-__global__ __launch_bounds__(256) void keypoints_kernel(const float* heat, int H, int W, float* kp) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
+constexpr int KT = 1024;        // 16 waves per plane: the sweep is latency-bound, it wants loads in flight
+
+__global__ __launch_bounds__(KT) void keypoints_kernel(const float* heat, int H, int W, float* kp) {
+    __shared__ float sv[KT / 64];
+    __shared__ int si[KT / 64];
     const float* pl = heat + (size_t)blockIdx.x * H * W;
     const int total = H * W;
     float bv = -INFINITY;
@@ -28,16 +30,16 @@ __global__ __launch_bounds__(256) void keypoints_kernel(const float* heat, int H
     const int nvec = total >> 2;
     const bool aligned = ((reinterpret_cast<uintptr_t>(pl) & 15) == 0);
     if (aligned) {
-        for (int v4 = threadIdx.x; v4 < nvec; v4 += 256) {
+        for (int v4 = threadIdx.x; v4 < nvec; v4 += KT) {
             const float4 q = reinterpret_cast<const float4*>(pl)[v4];
             take(q.x, v4 * 4 + 0, bv, bi);
             take(q.y, v4 * 4 + 1, bv, bi);
             take(q.z, v4 * 4 + 2, bv, bi);
             take(q.w, v4 * 4 + 3, bv, bi);
         }
-        for (int i = nvec * 4 + threadIdx.x; i < total; i += 256) take(pl[i], i, bv, bi);
+        for (int i = nvec * 4 + threadIdx.x; i < total; i += KT) take(pl[i], i, bv, bi);
     } else {
-        for (int i = threadIdx.x; i < total; i += 256) take(pl[i], i, bv, bi);
+        for (int i = threadIdx.x; i < total; i += KT) take(pl[i], i, bv, bi);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void keypoints_kernel(const float* heat, int H
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) take(sv[w], si[w], bv, bi);
+        for (int w = 1; w < KT / 64; ++w) take(sv[w], si[w], bv, bi);
         if (bi == 0x7fffffff) bi = 0;                        // all-NaN / all -inf plane
         const int px = bi % W, py = bi / W;
         float fx = (float)px, fy = (float)py;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void keypoints_kernel(const float* heat, int H
 
 int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, hipStream_t stream) {
     if (planes <= 0 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(keypoints_kernel, dim3((unsigned)planes), dim3(256), 0, stream, heat, H, W, kp);
+    hipLaunchKernelGGL(keypoints_kernel, dim3((unsigned)planes), dim3(KT), 0, stream, heat, H, W, kp);
     return (int)hipGetLastError();
 }
 
