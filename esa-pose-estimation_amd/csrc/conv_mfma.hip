@@ -537,7 +537,13 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
         if (p.Cinp > 32 && items16 < 2LL * 256 * 3 / 4 && p.OH > 8) return launch_t<3, 1, 8, 2>(p, stream);
         return launch_t<3, 1, 16, 2>(p, stream);
     }
-    if (k == 3 && stride == 2) return launch_t<3, 2, 4, 2>(p, stream);
+#ifndef ESA_S2C32
+#define ESA_S2C32 1
+#endif
+    if (k == 3 && stride == 2) {
+        if (ESA_S2C32 && conv_s2c32_supported(p)) return launch_conv_s2c32(p, stream);     // conv_s2c32.hip
+        return launch_t<3, 2, 4, 2>(p, stream);
+    }
     if (k == 1 && stride == 1) return launch_t<1, 1, 16, 2>(p, stream);
     return (int)hipErrorInvalidValue;
 }

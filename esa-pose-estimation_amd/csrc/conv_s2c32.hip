@@ -1,0 +1,196 @@
+// conv_s2c32.hip — 3x3 stride-2 convolution with 32 input channels (+ folded-BN bias, ReLU) on the
+// matrix cores, split-bf16: the first conv of every fuse-down chain and of transition1
+// (models/seg_hrnet.py:176-220 fuse_layers[i][j], j = 0 < i; :343-377 transition layers).
+//
+// A stride-2 conv reads four input pixels per output pixel, so the generic tiling (conv_mfma<3,2,4,2>:
+// one output row per wave, 32 couts per workgroup) is LDS- and L2-bound: 54 LDS reads per 54 MFMAs, and
+// the 9x33 input tile is staged once per 32-cout slice.  With a single 32-channel chunk the whole
+// weight set of a 16-cout tile is 18 fragments = 72 VGPRs, so here
+//   * a wave owns one cout tile for the workgroup's lifetime (persistent workgroups, cout-tile index
+//     constant per workgroup): its weights are loaded from global ONCE, never touch LDS;
+//   * every wave sweeps all rows of the pixel tile: each input-row fragment it reads from LDS feeds up to
+//     two taps of two output rows (54 reads per 108 MFMAs at 64 couts per workgroup);
+//   * the input tile is staged once per 64 (or 32) couts; the next item's tile is prefetched into
+//     registers while the current one is consumed (issue-early / write-late, as in conv_mfma.hip).
+// LDS holds only the 8 operand planes of the input tile (40 KB).
+#include "conv_cfg.h"
+#include "kernels.h"
+#include "sb.h"
+
+namespace esa {
+namespace {
+
+constexpr int S2_TH = 4;
+using S2C = ConvCfg<3, 2, S2_TH, 2>;
+
+// MW = cout tiles (of 16) per workgroup: 4 -> wave = cout tile, 4 output rows each;
+//                                        2 -> wave = (cout tile, row half), 2 output rows each
+template <int MW>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, int tiles_x, int tiles_y, int ctiles,
+                                                                int nitems) {
+    constexpr int RG = 4 / MW;                  // row groups
+    constexpr int NT = S2_TH / RG;              // output rows per wave
+    constexpr int ROWS = (NT - 1) * 2 + 3;      // input rows a wave touches
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;
+    const int mw = wave % MW, rg = wave / MW;
+    const int G = gridDim.x;
+    int item = xcd_contiguous(blockIdx.x, G);
+    if (item >= nitems) return;
+
+    // ---- staging map of the item being prefetched (same unit map as conv_mfma.hip) ---------------
+    int xg[S2C::XITER];
+    const int jst = tid & 7, q0 = tid >> 3;
+    char* xwr = xs + S2C::plane_off(jst) + q0 * 16;
+    const char* xn;
+    int s_n, s_oy0, s_ox0, s_ct;
+#define S2_DECODE(ITEM)                                                                           \
+    {                                                                                             \
+        int b_ = (ITEM);                                                                          \
+        s_ct = b_ % ctiles; b_ /= ctiles;                                                         \
+        const int tx_ = b_ % tiles_x; b_ /= tiles_x;                                              \
+        const int ty_ = b_ % tiles_y;                                                             \
+        s_n = b_ / tiles_y;                                                                       \
+        s_oy0 = ty_ * S2_TH; s_ox0 = tx_ * TW;                                                    \
+        xn = p.x + (size_t)s_n * p.H * p.W * 128;                                                 \
+        _Pragma("unroll") for (int it = 0; it < S2C::XITER; ++it) {                               \
+            const int q = q0 + it * 32;                                                           \
+            const int qy = q / S2C::IW, qx = q - qy * S2C::IW;                                    \
+            const int gy = s_oy0 * 2 - 1 + qy, gx = s_ox0 * 2 - 1 + qx;                           \
+            const bool inside = q < S2C::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;      \
+            xg[it] = inside ? ((gy * p.W + gx) * 128 + jst * 16) : -1;                            \
+        }                                                                                         \
+    }
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    u32x4 xr[S2C::XITER];
+#define S2_PREFETCH()                                                                             \
+    {                                                                                             \
+        _Pragma("unroll") for (int it = 0; it < S2C::XITER; ++it) {                               \
+            u32x4 v = {0, 0, 0, 0};                                                               \
+            if (xg[it] >= 0) v = *reinterpret_cast<const u32x4*>(xn + xg[it]);                    \
+            xr[it] = v;                                                                           \
+        }                                                                                         \
+    }
+
+    const char* xrd = xs + S2C::plane_off(2 * g) + ((rg * NT * 2) * S2C::IW + (lane & 15) * 2) * 16;
+    const int opix = p.Coutp * 4;
+    bf16x8 wh[9], wl[9];
+    int wct = -1;                               // cout-tile slice whose weights are in registers
+
+    S2_DECODE(item)
+    S2_PREFETCH()
+    bool first = true;
+    while (item < nitems) {
+        const int n = s_n, oy0 = s_oy0, ox0 = s_ox0, ct = s_ct;
+        const int next = item + G;
+        if (ct != wct) {                        // once per workgroup when ctiles divides the grid
+            const uint4* wsrc = p.w + (size_t)(ct * MW + mw) * (9 * 128) + lane;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                wh[tap] = __builtin_bit_cast(bf16x8, wsrc[(tap * 2 + 0) * 64]);
+                wl[tap] = __builtin_bit_cast(bf16x8, wsrc[(tap * 2 + 1) * 64]);
+            }
+            wct = ct;
+        }
+        if (!first) __syncthreads();            // previous item's MFMAs are done reading the planes
+        first = false;
+#pragma unroll
+        for (int it = 0; it < S2C::XITER; ++it)
+            if (q0 + it * 32 < S2C::NPIX) *reinterpret_cast<u32x4*>(xwr + it * 512) = xr[it];
+        __syncthreads();
+        if (next < nitems) {
+            S2_DECODE(next)
+            S2_PREFETCH()
+        }
+        const int co = (ct * MW + mw) * 16 + g * 4;
+        f32x4 acc[NT];
+        {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = bv;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                const int off = (i * S2C::IW + kx) * 16;
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xrd + off);
+                const bf16x8 xo = *reinterpret_cast<const bf16x8*>(xrd + off + S2C::LO_OFF);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int d = i - ky;
+                    if (d >= 0 && (d & 1) == 0 && d / 2 < NT) {
+                        const int t = d / 2;
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ky * 3 + kx], xh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xo, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xh, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        // ---- epilogue: ReLU, split, 16-byte chunk stores -------------------------------------------
+        const int ox = ox0 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int oy = oy0 + rg * NT + t;
+            float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+            if (p.relu) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
+            }
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            const uint4 ch = quad_to_chunk(hi, lo);
+            if (oy < p.OH && ox < p.OW)
+                *reinterpret_cast<uint4*>(p.y + ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + chunk_ofs(co, g)) = ch;
+        }
+        item = next;
+    }
+#undef S2_DECODE
+#undef S2_PREFETCH
+}
+
+template <int MW>
+int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
+    auto kern = conv_s2c32_kernel<MW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, S2C::XBYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + S2_TH - 1) / S2_TH;
+    const int ctiles = p.Coutp / (16 * MW);
+    const long long nitems = (long long)p.N * tiles_y * tiles_x * ctiles;
+    if (nitems <= 0 || nitems > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        }
+        slots = 2 * cus;
+    }
+    int grid = (int)(nitems < slots ? nitems : slots);
+    if (grid > ctiles) grid -= grid % ctiles;   // grid stride keeps the cout slice of a workgroup constant
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), S2C::XBYTES, stream, p, tiles_x, tiles_y, ctiles,
+                       (int)nitems);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool conv_s2c32_supported(const ConvParams& p) {
+    return p.Cinp == 32 && (p.Coutp & 31) == 0 && !p.res && !p.out_f32 &&
+           (long long)p.H * p.W * 128 <= 0x7fffffffLL;
+}
+
+int launch_conv_s2c32(const ConvParams& p, hipStream_t stream) {
+    if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
+    return (p.Coutp % 64 == 0) ? launch_s2c32_t<4>(p, stream) : launch_s2c32_t<2>(p, stream);
+}
+
+}  // namespace esa
