@@ -1,6 +1,6 @@
-// conv_s2c32.hip — 3x3 stride-2 convolution with 32 input channels (+ folded-BN bias, ReLU) on the
-// matrix cores, split-bf16: the first conv of every fuse-down chain and of transition1
-// (models/seg_hrnet.py:176-220 fuse_layers[i][j], j = 0 < i; :343-377 transition layers).
+// conv_s2c32.hip — 3x3 stride-2 convolution (+ folded-BN bias, ReLU) on the matrix cores, split-bf16,
+// weights in registers: the fuse-down chains and the transition layers
+// (models/seg_hrnet.py:176-220 fuse_layers[i][j], j < i; :343-377 transition layers).
 //
 // A stride-2 conv reads four input pixels per output pixel, so the generic tiling (conv_mfma<3,2,4,2>:
 // one output row per wave, 32 couts per workgroup) is LDS- and L2-bound: 54 LDS reads per 54 MFMAs, and
@@ -25,6 +25,10 @@ using S2C = ConvCfg<3, 2, S2_TH, 2>;
 
 // MW = cout tiles (of 16) per workgroup: 4 -> wave = cout tile, 4 output rows each;
 //                                        2 -> wave = (cout tile, row half), 2 output rows each
+// The workgroup walks a stream of (item, chunk) steps; X of step s+1 is prefetched into registers while
+// step s is consumed; the weight registers are a ring of three kx-thirds: as soon as phase kx of step s
+// is done, the (kx) third of step s+1 is loaded into the same registers (3 phases of cover, no extra
+// VGPRs).  Single-chunk layers whose cout slice does not change keep their weights for the whole launch.
 template <int MW>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, int tiles_x, int tiles_y, int ctiles,
                                                                 int nitems) {
@@ -37,6 +41,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
     const int g = lane >> 4;
     const int mw = wave % MW, rg = wave / MW;
     const int G = gridDim.x;
+    const int nchunks = p.Cinp >> 5;
+    const int pixb = p.Cinp * 4;
     int item = xcd_contiguous(blockIdx.x, G);
     if (item >= nitems) return;
 
@@ -54,65 +60,76 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
         const int ty_ = b_ % tiles_y;                                                             \
         s_n = b_ / tiles_y;                                                                       \
         s_oy0 = ty_ * S2_TH; s_ox0 = tx_ * TW;                                                    \
-        xn = p.x + (size_t)s_n * p.H * p.W * 128;                                                 \
+        xn = p.x + (size_t)s_n * p.H * p.W * pixb;                                                \
         _Pragma("unroll") for (int it = 0; it < S2C::XITER; ++it) {                               \
             const int q = q0 + it * 32;                                                           \
             const int qy = q / S2C::IW, qx = q - qy * S2C::IW;                                    \
             const int gy = s_oy0 * 2 - 1 + qy, gx = s_ox0 * 2 - 1 + qx;                           \
             const bool inside = q < S2C::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;      \
-            xg[it] = inside ? ((gy * p.W + gx) * 128 + jst * 16) : -1;                            \
+            xg[it] = inside ? ((gy * p.W + gx) * pixb + jst * 16) : -1;                           \
         }                                                                                         \
     }
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     u32x4 xr[S2C::XITER];
-#define S2_PREFETCH()                                                                             \
+#define S2_PREFETCH(CH)                                                                           \
     {                                                                                             \
         _Pragma("unroll") for (int it = 0; it < S2C::XITER; ++it) {                               \
             u32x4 v = {0, 0, 0, 0};                                                               \
-            if (xg[it] >= 0) v = *reinterpret_cast<const u32x4*>(xn + xg[it]);                    \
+            if (xg[it] >= 0) v = *reinterpret_cast<const u32x4*>(xn + xg[it] + (CH) * 128);       \
             xr[it] = v;                                                                           \
+        }                                                                                         \
+    }
+    // weights of (cout slice CT, chunk CH), third KX -> registers wh/wl[ky*3 + KX]
+#define S2_LOAD_W(CT, CH, KX)                                                                     \
+    {                                                                                             \
+        const uint4* ws_ = p.w + ((size_t)((CT) * MW + mw) * nchunks + (CH)) * (9 * 128) + lane;  \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                        \
+            wh[ky * 3 + (KX)] = __builtin_bit_cast(bf16x8, ws_[((ky * 3 + (KX)) * 2 + 0) * 64]);  \
+            wl[ky * 3 + (KX)] = __builtin_bit_cast(bf16x8, ws_[((ky * 3 + (KX)) * 2 + 1) * 64]);  \
         }                                                                                         \
     }
 
     const char* xrd = xs + S2C::plane_off(2 * g) + ((rg * NT * 2) * S2C::IW + (lane & 15) * 2) * 16;
     const int opix = p.Coutp * 4;
     bf16x8 wh[9], wl[9];
-    int wct = -1;                               // cout-tile slice whose weights are in registers
 
     S2_DECODE(item)
-    S2_PREFETCH()
+    S2_PREFETCH(0)
+    S2_LOAD_W(s_ct, 0, 0)
+    S2_LOAD_W(s_ct, 0, 1)
+    S2_LOAD_W(s_ct, 0, 2)
+    int n = s_n, oy0 = s_oy0, ox0 = s_ox0, ct = s_ct;      // the item being computed
+    int c = 0;
     bool first = true;
-    while (item < nitems) {
-        const int n = s_n, oy0 = s_oy0, ox0 = s_ox0, ct = s_ct;
-        const int next = item + G;
-        if (ct != wct) {                        // once per workgroup when ctiles divides the grid
-            const uint4* wsrc = p.w + (size_t)(ct * MW + mw) * (9 * 128) + lane;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                wh[tap] = __builtin_bit_cast(bf16x8, wsrc[(tap * 2 + 0) * 64]);
-                wl[tap] = __builtin_bit_cast(bf16x8, wsrc[(tap * 2 + 1) * 64]);
-            }
-            wct = ct;
-        }
-        if (!first) __syncthreads();            // previous item's MFMAs are done reading the planes
+    f32x4 acc[NT];
+    while (true) {
+        const bool last_chunk = c + 1 == nchunks;
+        const bool more = !last_chunk || item + G < nitems;          // is there a step s+1?
+        if (!first) __syncthreads();            // previous step's MFMAs are done reading the planes
         first = false;
 #pragma unroll
         for (int it = 0; it < S2C::XITER; ++it)
             if (q0 + it * 32 < S2C::NPIX) *reinterpret_cast<u32x4*>(xwr + it * 512) = xr[it];
         __syncthreads();
-        if (next < nitems) {
-            S2_DECODE(next)
-            S2_PREFETCH()
+        // step s+1: next chunk of this item, or chunk 0 of the workgroup's next item
+        int nct = ct, nch = c + 1;
+        if (last_chunk) {
+            nch = 0;
+            if (more) {
+                S2_DECODE(item + G)
+                nct = s_ct;
+            }
         }
+        if (more) S2_PREFETCH(nch)
+        const bool reload = more && (nchunks > 1 || nct != ct);
         const int co = (ct * MW + mw) * 16 + g * 4;
-        f32x4 acc[NT];
-        {
+        if (c == 0) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = bv;
         }
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) {
                 const int off = (i * S2C::IW + kx) * 16;
@@ -129,26 +146,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
                     }
                 }
             }
-        // ---- epilogue: ReLU, split, 16-byte chunk stores -------------------------------------------
-        const int ox = ox0 + (lane & 15);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int oy = oy0 + rg * NT + t;
-            float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-            if (p.relu) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
-            }
-            uint2 hi, lo;
-            split4(v, hi, lo);
-            const uint4 ch = quad_to_chunk(hi, lo);
-            if (oy < p.OH && ox < p.OW)
-                *reinterpret_cast<uint4*>(p.y + ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + chunk_ofs(co, g)) = ch;
+            if (reload) S2_LOAD_W(nct, nch, kx)     // this third is free: refill it for step s+1
         }
-        item = next;
+        if (last_chunk) {
+            // ---- epilogue: ReLU, split, 16-byte chunk stores ---------------------------------------
+            const int ox = ox0 + (lane & 15);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int oy = oy0 + rg * NT + t;
+                float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+                if (p.relu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
+                }
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                const uint4 ch = quad_to_chunk(hi, lo);
+                if (oy < p.OH && ox < p.OW)
+                    *reinterpret_cast<uint4*>(p.y + ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + chunk_ofs(co, g)) = ch;
+            }
+            if (!more) break;
+            item += G;
+            n = s_n; oy0 = s_oy0; ox0 = s_ox0; ct = s_ct;
+            c = 0;
+        } else {
+            ++c;
+        }
     }
 #undef S2_DECODE
 #undef S2_PREFETCH
+#undef S2_LOAD_W
 }
 
 template <int MW>
@@ -184,8 +211,8 @@ int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
 }  // namespace
 
 bool conv_s2c32_supported(const ConvParams& p) {
-    return p.Cinp == 32 && (p.Coutp & 31) == 0 && !p.res && !p.out_f32 &&
-           (long long)p.H * p.W * 128 <= 0x7fffffffLL;
+    return (p.Cinp & 31) == 0 && p.Cinp >= 32 && (p.Coutp & 31) == 0 && !p.res && !p.out_f32 &&
+           (long long)p.H * p.W * p.Cinp * 4 <= 0x7fffffffLL;
 }
 
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream) {
