@@ -530,7 +530,16 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
     if ((p.Cinp & 31) || (p.Coutp & 31)) return (int)hipErrorInvalidValue;
     // one image is addressed with 32-bit byte offsets inside the kernel
     if ((long long)p.H * p.W * p.Cinp * 4 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+#ifndef ESA_S1W
+#define ESA_S1W 1
+#endif
     if (k == 3 && stride == 1) {
+        // layers with many 16x16x32-cout items per image (>= two per workgroup slot at batch 32): the register-weight stream kernel
+        // (conv_s2c32.hip; measured 5-15 % faster there: cross-item prefetch, two barriers per chunk, no
+        // weight traffic through LDS); smaller grids stay on the LDS weight ring below
+        // (the choice must not depend on the batch size: a crop's result is bit-identical in any batch)
+        const long long items_per_image = (long long)((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);
+        if (ESA_S1W && p.Cinp > 32 && items_per_image >= 32 && conv_s2c32_supported(p)) return launch_conv_s1w(p, stream);
         // deep, small-resolution layers (e.g. 256 ch @ 16x16, batch 32) have too few 16x16 tiles to
         // fill 2 workgroups on every CU: halve the tile height there
         const long long items16 = (long long)p.N * ((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);

@@ -20,8 +20,6 @@
 namespace esa {
 namespace {
 
-constexpr int S2_TH = 4;
-using S2C = ConvCfg<3, 2, S2_TH, 2>;
 
 // MW = cout tiles (of 16) per workgroup: 4 -> wave = cout tile, 4 output rows each;
 //                                        2 -> wave = (cout tile, row half), 2 output rows each
@@ -29,12 +27,14 @@ using S2C = ConvCfg<3, 2, S2_TH, 2>;
 // step s is consumed; the weight registers are a ring of three kx-thirds: as soon as phase kx of step s
 // is done, the (kx) third of step s+1 is loaded into the same registers (3 phases of cover, no extra
 // VGPRs).  Single-chunk layers whose cout slice does not change keep their weights for the whole launch.
-template <int MW>
+template <int S, int TH, int MW>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, int tiles_x, int tiles_y, int ctiles,
                                                                 int nitems) {
+    using S2C = ConvCfg<3, S, TH, 2>;
+    constexpr int S2_TH = TH;
     constexpr int RG = 4 / MW;                  // row groups
     constexpr int NT = S2_TH / RG;              // output rows per wave
-    constexpr int ROWS = (NT - 1) * 2 + 3;      // input rows a wave touches
+    constexpr int ROWS = (NT - 1) * S + 3;      // input rows a wave touches
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
         _Pragma("unroll") for (int it = 0; it < S2C::XITER; ++it) {                               \
             const int q = q0 + it * 32;                                                           \
             const int qy = q / S2C::IW, qx = q - qy * S2C::IW;                                    \
-            const int gy = s_oy0 * 2 - 1 + qy, gx = s_ox0 * 2 - 1 + qx;                           \
+            const int gy = s_oy0 * S - 1 + qy, gx = s_ox0 * S - 1 + qx;                           \
             const bool inside = q < S2C::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;      \
             xg[it] = inside ? ((gy * p.W + gx) * pixb + jst * 16) : -1;                           \
         }                                                                                         \
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
         }                                                                                         \
     }
 
-    const char* xrd = xs + S2C::plane_off(2 * g) + ((rg * NT * 2) * S2C::IW + (lane & 15) * 2) * 16;
+    const char* xrd = xs + S2C::plane_off(2 * g) + ((rg * NT * S) * S2C::IW + (lane & 15) * S) * 16;
     const int opix = p.Coutp * 4;
     bf16x8 wh[9], wl[9];
 
@@ -128,6 +128,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = bv;
         }
+        // residual (last chunk only): two halves of the wave's rows, each loaded a phase or two before it
+        // is folded into the accumulators, as 16-byte chunks (sb.h)
+        constexpr int NH = NT >= 2 ? NT / 2 : 1;
+        uint4 rc[NH];
+        const bool do_res = last_chunk && p.res != nullptr;
+        const int rox = ox0 + (lane & 15);
+#define S2_RES_LOAD(HALF)                                                                         \
+        if (do_res) {                                                                             \
+            _Pragma("unroll") for (int t = 0; t < NH; ++t) {                                      \
+                const int oy_ = oy0 + rg * NT + (HALF) * NH + t;                                  \
+                rc[t] = make_uint4(0, 0, 0, 0);                                                   \
+                if ((HALF) * NH + t < NT && oy_ < p.OH && rox < p.OW)                             \
+                    rc[t] = *reinterpret_cast<const uint4*>(p.res + ((size_t)(n * p.OH + oy_) * p.OW + rox) * opix + chunk_ofs(co, g)); \
+            }                                                                                     \
+        }
+#define S2_RES_ADD(HALF)                                                                          \
+        if (do_res) {                                                                             \
+            _Pragma("unroll") for (int t = 0; t < NH; ++t)                                        \
+                if ((HALF) * NH + t < NT) {                                                       \
+                    uint2 rh_, rl_;                                                               \
+                    chunk_to_quad(rc[t], rh_, rl_);                                               \
+                    float r_[4];                                                                  \
+                    join4(rh_, rl_, r_);                                                          \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[(HALF) * NH + t][i] += r_[i]; \
+                }                                                                                 \
+        }
+        S2_RES_LOAD(0)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
@@ -138,8 +165,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int d = i - ky;
-                    if (d >= 0 && (d & 1) == 0 && d / 2 < NT) {
-                        const int t = d / 2;
+                    if (d >= 0 && d % S == 0 && d / S < NT) {
+                        const int t = d / S;
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ky * 3 + kx], xh, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xo, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xh, acc[t], 0, 0, 0);
@@ -147,7 +174,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
                 }
             }
             if (reload) S2_LOAD_W(nct, nch, kx)     // this third is free: refill it for step s+1
+            if (kx == 1) {
+                S2_RES_ADD(0)
+                if (NT >= 2) S2_RES_LOAD(1)
+            }
+            if (kx == 2 && NT >= 2) S2_RES_ADD(1)
         }
+#undef S2_RES_LOAD
+#undef S2_RES_ADD
         if (last_chunk) {
             // ---- epilogue: ReLU, split, 16-byte chunk stores ---------------------------------------
             const int ox = ox0 + (lane & 15);
@@ -178,9 +212,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
 #undef S2_LOAD_W
 }
 
-template <int MW>
+template <int S, int TH, int MW>
 int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
-    auto kern = conv_s2c32_kernel<MW>;
+    using S2C = ConvCfg<3, S, TH, 2>;
+    constexpr int S2_TH = TH;
+    auto kern = conv_s2c32_kernel<S, TH, MW>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -211,13 +247,19 @@ int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
 }  // namespace
 
 bool conv_s2c32_supported(const ConvParams& p) {
-    return (p.Cinp & 31) == 0 && p.Cinp >= 32 && (p.Coutp & 31) == 0 && !p.res && !p.out_f32 &&
+    return (p.Cinp & 31) == 0 && p.Cinp >= 32 && (p.Coutp & 31) == 0 && !p.out_f32 &&
            (long long)p.H * p.W * p.Cinp * 4 <= 0x7fffffffLL;
 }
 
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream) {
     if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
-    return (p.Coutp % 64 == 0) ? launch_s2c32_t<4>(p, stream) : launch_s2c32_t<2>(p, stream);
+    return (p.Coutp % 64 == 0) ? launch_s2c32_t<2, 4, 4>(p, stream) : launch_s2c32_t<2, 4, 2>(p, stream);
+}
+
+// the same scheme for stride 1 (TH = 16, a wave = one cout tile x 8 rows, 32 couts per workgroup)
+int launch_conv_s1w(const ConvParams& p, hipStream_t stream) {
+    if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
+    return launch_s2c32_t<1, 16, 2>(p, stream);
 }
 
 }  // namespace esa

@@ -22,6 +22,7 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream);
 // 3x3 stride-2, Cinp == 32, no residual: weights in registers, one cout tile per wave (conv_s2c32.hip)
 bool conv_s2c32_supported(const ConvParams& p);
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream);
+int launch_conv_s1w(const ConvParams& p, hipStream_t stream);
 // bytes of the packed weight image for a conv with padded channel counts
 size_t packed_weight_bytes(int coutp, int cinp, int k);
 // host-side packing: w f32 [cout][cin][k][k] -> dst (packed_weight_bytes), zero padded
