@@ -1,0 +1,140 @@
+// conv1x1.hip — 1x1 convolution (+ folded-BN bias, optional ReLU) for the small fuse-up layers:
+// fuse_layers[i][j], j > i (models/seg_hrnet.py:176-220: 1x1 conv + BN on the low-resolution branch,
+// up-sampled afterwards by fuse.hip).
+//
+// These layers are tiny (256 -> 32 channels on a 16x16 grid is 67 MFLOP per batch) and the tiled kernel
+// of conv_mfma.hip walks their input channels in 32-wide chunks, one global -> LDS round trip per chunk:
+// 8 serial round trips for 0.2 us of math.  Here a wave owns 16 pixels of a row and holds ALL their
+// input channels in registers (one round trip, B operand: columns = pixels); the weights stream through
+// LDS one 32-cout chunk at a time (A operand: rows = output channels), the next chunk's fragments in
+// flight while the current one is consumed.  D[cout][pixel] leaves 4 consecutive channels of a pixel
+// per lane: 16-byte SB chunk stores (sb.h).
+#include "kernels.h"
+#include "sb.h"
+
+namespace esa {
+namespace {
+
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long ntiles, int tiles_per_row) {
+    constexpr int WFR = 4 * NCH;                   // 1-KB weight fragments per 32-cout chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const long long tile = (long long)xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
+    const bool live = tile < ntiles;
+    const int k = (int)(tile % tiles_per_row);
+    const long long row = tile / tiles_per_row;                 // n*H + y
+    const int col = k * 16 + i;
+    const bool valid = live && col < p.W;
+    const int nchunks = p.Coutp >> 5;
+
+    bf16x8 xh[NCH], xl[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        uint4 h = make_uint4(0, 0, 0, 0), l = make_uint4(0, 0, 0, 0);
+        if (valid) {
+            const char* a = p.x + ((size_t)row * p.W + col) * (size_t)(p.Cinp * 4) + c * 128 + g * 32;
+            h = *reinterpret_cast<const uint4*>(a);
+            l = *reinterpret_cast<const uint4*>(a + 16);
+        }
+        xh[c] = __builtin_bit_cast(bf16x8, h);
+        xl[c] = __builtin_bit_cast(bf16x8, l);
+    }
+
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
+    u32x4 wreg[NCH];
+#define C1_PREFETCH(CH)                                                                       \
+    {                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < NCH; ++it)                                    \
+            wreg[it] = wsrc[(size_t)(CH) * WFR * 64 + it * 256 + tid];                        \
+    }
+#define C1_COMMIT(BUF)                                                                        \
+    {                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < NCH; ++it)                                    \
+            *reinterpret_cast<u32x4*>(smem + (BUF) * (WFR * 1024) + (it * 256 + tid) * 16) = wreg[it]; \
+    }
+    C1_PREFETCH(0)
+    C1_COMMIT(0)
+    __syncthreads();
+    char* orow = p.y + ((size_t)row * p.W + col) * (size_t)(p.Coutp * 4);
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const int buf = cc & 1;
+        if (cc + 1 < nchunks) C1_PREFETCH(cc + 1)
+        const char* wb = smem + buf * (WFR * 1024) + lane * 16;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int co = cc * 32 + m * 16 + g * 4;
+            f32x4 d = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wb + ((m * NCH + c) * 2 + 0) * 1024);
+                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wb + ((m * NCH + c) * 2 + 1) * 1024);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[c], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[c], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[c], d, 0, 0, 0);
+            }
+            float v[4] = {d[0], d[1], d[2], d[3]};
+            {
+                const int rfl = relu_floor(p.relu);          // branch-free (see sb.h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = relu_opt(v[r], rfl);
+            }
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            const uint4 ch = quad_to_chunk(hi, lo);
+            if (valid) *reinterpret_cast<uint4*>(orow + chunk_ofs(co, g)) = ch;
+        }
+        if (cc + 1 < nchunks) {
+            C1_COMMIT(buf ^ 1)
+            __syncthreads();
+        }
+    }
+#undef C1_PREFETCH
+#undef C1_COMMIT
+}
+
+template <int NCH>
+int launch_conv1x1_n(const ConvParams& p, hipStream_t stream) {
+    auto kern = conv1x1_kernel<NCH>;
+    const int lds = 2 * 4 * NCH * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles_per_row = (p.W + 15) / 16;
+    const long long ntiles = (long long)p.N * p.H * tiles_per_row;
+    const long long nblk = (ntiles + 3) / 4;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, p, ntiles, tiles_per_row);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// weights must be packed with pack_conv_weights(k = 1): [Coutp/16][Cinp/32][hi|lo][64] fragments — the
+// 4*NCH fragments of a 32-cout chunk are contiguous, which is what the staging above relies on
+bool conv1x1_supported(const ConvParams& p) {
+    const int n = p.Cinp / 32;
+    return (p.Cinp % 32) == 0 && (p.Coutp % 32) == 0 && !p.res && !p.out_f32 && p.H == p.OH && p.W == p.OW &&
+           (n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12);
+}
+
+int launch_conv1x1(const ConvParams& p, hipStream_t stream) {
+    if (!conv1x1_supported(p)) return (int)hipErrorInvalidValue;
+    switch (p.Cinp / 32) {
+        case 2: return launch_conv1x1_n<2>(p, stream);
+        case 3: return launch_conv1x1_n<3>(p, stream);
+        case 4: return launch_conv1x1_n<4>(p, stream);
+        case 6: return launch_conv1x1_n<6>(p, stream);
+        case 8: return launch_conv1x1_n<8>(p, stream);
+        case 12: return launch_conv1x1_n<12>(p, stream);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace esa

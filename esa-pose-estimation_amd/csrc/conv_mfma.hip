@@ -248,9 +248,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(ConvParams p, in
                 const int oy = oy0 + wave * C::NT + t;
                 const bool inr = (ESA_DO_STORE || acc[m][t][0] == 123.456f) && oy < p.OH && ox < p.OW;
                 float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
-                if (p.relu) {
+                {
+                    const int rfl = relu_floor(p.relu);          // branch-free (see sb.h)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
+                    for (int i = 0; i < 4; ++i) v[i] = relu_opt(v[i], rfl);
                 }
                 if (p.out_f32) {
                     const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
@@ -437,9 +438,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_ring_kernel(ConvParams 
             const int oy = oy0 + wave * C::NT + t;
             const bool inr = (ESA_DO_STORE || acc[m][t][0] == 123.456f) && oy < p.OH && ox < p.OW;
             float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
-            if (p.relu) {
+            {
+                const int rfl = relu_floor(p.relu);          // branch-free (see sb.h)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
+                for (int i = 0; i < 4; ++i) v[i] = relu_opt(v[i], rfl);
             }
             if (p.out_f32) {
                 const size_t of = ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + (size_t)co * 4;
@@ -553,7 +555,13 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
         if (ESA_S2C32 && conv_s2c32_supported(p)) return launch_conv_s2c32(p, stream);     // conv_s2c32.hip
         return launch_t<3, 2, 4, 2>(p, stream);
     }
-    if (k == 1 && stride == 1) return launch_t<1, 1, 16, 2>(p, stream);
+#ifndef ESA_C1X1
+#define ESA_C1X1 1
+#endif
+    if (k == 1 && stride == 1) {
+        if (ESA_C1X1 && conv1x1_supported(p)) return launch_conv1x1(p, stream);          // conv1x1.hip
+        return launch_t<1, 1, 16, 2>(p, stream);
+    }
     return (int)hipErrorInvalidValue;
 }
 

@@ -189,9 +189,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
             for (int t = 0; t < NT; ++t) {
                 const int oy = oy0 + rg * NT + t;
                 float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-                if (p.relu) {
+                {
+                    const int rfl = relu_floor(p.relu);          // branch-free (see sb.h)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
+                    for (int i = 0; i < 4; ++i) v[i] = relu_opt(v[i], rfl);
                 }
                 uint2 hi, lo;
                 split4(v, hi, lo);

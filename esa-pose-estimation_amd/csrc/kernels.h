@@ -23,6 +23,9 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream);
 bool conv_s2c32_supported(const ConvParams& p);
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream);
 int launch_conv_s1w(const ConvParams& p, hipStream_t stream);
+// 1x1, Cinp in {64..384}: all input channels of 16 pixels in registers, weights streamed through LDS (conv1x1.hip)
+bool conv1x1_supported(const ConvParams& p);
+int launch_conv1x1(const ConvParams& p, hipStream_t stream);
 // bytes of the packed weight image for a conv with padded channel counts
 size_t packed_weight_bytes(int coutp, int cinp, int k);
 // host-side packing: w f32 [cout][cin][k][k] -> dst (packed_weight_bytes), zero padded

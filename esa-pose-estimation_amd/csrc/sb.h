@@ -61,6 +61,16 @@ __device__ __forceinline__ float relu1(float v) {
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
+// Optional ReLU without a branch: floor = relu_floor(flag) is 0 (ReLU) or INT_MIN (identity), one v_max_i32.
+// Keep it branch-free on purpose: with `if (relu) {...}` right behind the last MFMA of an accumulator, hipcc
+// (ROCm 7.2) pads the MFMA -> VALU read hazard with s_nop only on the taken path, and the fall-through path
+// reads the accumulator registers too early (observed: wrong low-order bits in the first two channels).
+__device__ __forceinline__ int relu_floor(int relu) { return relu ? 0 : (int)0x80000000; }
+__device__ __forceinline__ float relu_opt(float v, int floor) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > floor ? b : floor);
+}
+
 // 4 floats -> 8 bytes of hi bf16 + 8 bytes of lo bf16
 __device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
     split2(v[0], v[1], hi.x, lo.x);
