@@ -18,7 +18,13 @@ for f in sorted(glob.glob(os.path.join(root, "pass*", "*", "*_counter_collection
         n = r["Kernel_Name"].replace("(anonymous namespace)::", "")
         if "esa::" not in n:
             continue
-        if "conv_mfma_ring_kernel<1" in n:            # ring kernel template args are <stride, TH, MT>, always 3x3
+        if "conv_s2c32_kernel<1" in n:                # stream kernel template args are <stride, TH, MW>, always 3x3
+            key = "conv_mfma<3,1>"
+        elif "conv_s2c32_kernel<2" in n:
+            key = "conv_mfma<3,2>"
+        elif "conv1x1_kernel" in n:
+            key = "conv_mfma<1,1>"
+        elif "conv_mfma_ring_kernel<1" in n:          # ring kernel template args are <stride, TH, MT>, always 3x3
             key = "conv_mfma<3,1>"
         elif "conv_mfma_ring_kernel<2" in n:
             key = "conv_mfma<3,2>"
