@@ -221,7 +221,7 @@ def test_intermediate_tensors_match_oracle(env):
     print(f"worst intermediate Linf {worst:.3e} over {len(taps_ref)} tensors")
 
 
-@pytest.mark.parametrize("hw", [(48, 80), (40, 56), (16, 16), (18, 34)])
+@pytest.mark.parametrize("hw", [(48, 80), (40, 56), (16, 16), (18, 34), (104, 72), (128, 160)])
 def test_odd_shapes_match_oracle(env, hw):
     net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 6)
     x = env["synth"].make_crops(2, 1, hw[0], hw[1], seed=6)
