@@ -541,7 +541,9 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
         // weight traffic through LDS); smaller grids stay on the LDS weight ring below
         // (the choice must not depend on the batch size: a crop's result is bit-identical in any batch)
         const long long items_per_image = (long long)((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);
-        if (ESA_S1W && items_per_image >= 32 && conv_s2c32_supported(p)) return launch_conv_s1w(p, stream);
+        // (deep contractions amortise the ring's prologue and share each weight chunk between four waves through
+        // LDS: the 480 -> 480 3x3 of seg_hrnet3 runs 432 TFLOP/s on the ring, 396 on the stream kernel)
+        if (ESA_S1W && items_per_image >= 32 && p.Cinp <= 128 && conv_s2c32_supported(p)) return launch_conv_s1w(p, stream);
         // deep, small-resolution layers (e.g. 256 ch @ 16x16, batch 32) have too few 16x16 tiles to
         // fill 2 workgroups on every CU: halve the tile height there
         const long long items16 = (long long)p.N * ((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);
