@@ -56,19 +56,33 @@ __global__ __launch_bounds__(256) void ca_mlp_kernel(const float* partial, const
                                                      float* ca, int HW, int C, int Cp, int Cr, int P) {
     __shared__ float avg[512], mx[512], ha[64], hm[64];
     const int n = blockIdx.x, tid = threadIdx.x;
+    // finish the pooling: 8 slabs per step so that 8 loads are in flight (one dependent round trip per slab
+    // made this kernel 18 us of pure latency); slab order of the sum is kept
     for (int c = tid; c < Cp; c += 256) {
         float a = 0.f, b = -INFINITY;
-        for (int s = 0; s < P; ++s) {
-            const float* q = partial + (((size_t)n * P + s) * Cp + c) * 2;
-            a += q[0]; b = fmaxf(b, q[1]);
+        const float2* q = reinterpret_cast<const float2*>(partial) + (size_t)n * P * Cp + c;
+        int s = 0;
+        for (; s + 8 <= P; s += 8) {
+            float2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = q[(size_t)(s + k) * Cp];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a += v[k].x; b = fmaxf(b, v[k].y); }
         }
+        for (; s < P; ++s) { const float2 v = q[(size_t)s * Cp]; a += v.x; b = fmaxf(b, v.y); }
         avg[c] = a / (float)HW; mx[c] = b;
     }
     __syncthreads();
-    if (tid < Cr) {                       // fc[0] (no bias) + ReLU, on both pooled vectors
+    // fc[0] (no bias) + ReLU on both pooled vectors: 16 lanes per hidden unit, strided over the channels,
+    // then a 16-lane butterfly (a single thread per unit walked all C channels serially: 18 us per launch)
+    for (int j0 = 0; j0 < Cr; j0 += 16) {
+        const int j = j0 + (tid >> 4), l = tid & 15;
         float a = 0.f, b = 0.f;
-        for (int c = 0; c < C; ++c) { a += w0[tid * C + c] * avg[c]; b += w0[tid * C + c] * mx[c]; }
-        ha[tid] = fmaxf(a, 0.f); hm[tid] = fmaxf(b, 0.f);
+        if (j < Cr)
+            for (int c = l; c < C; c += 16) { const float wv = w0[j * C + c]; a += wv * avg[c]; b += wv * mx[c]; }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 16); b += __shfl_xor(b, off, 16); }
+        if (j < Cr && l == 0) { ha[j] = fmaxf(a, 0.f); hm[j] = fmaxf(b, 0.f); }
     }
     __syncthreads();
     for (int c = tid; c < Cp; c += 256) {
