@@ -138,25 +138,29 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(CbamApplyParams p, long
     const bool live = pl < PPB && idx < npix;
     const int HW = p.H * p.W;
     int n = 0;
+    float part = 0.f;
     if (live) {
+        // the 49 taps of the pixel's 7x7 spatial attention are spread over its G threads (a single thread
+        // walking all of them serialised 49 dependent loads while the others waited at the barrier)
         n = (int)(idx / HW);
-        if (c8 == 0) {
-            const int pix = (int)(idx - (long long)n * HW);
-            const int y = pix / p.W, x = pix - y * p.W;
-            float acc = 0.f;
-            for (int ky = 0; ky < 7; ++ky) {
-                const int yy = y + ky - 3;
-                if (yy < 0 || yy >= p.H) continue;
-                for (int kx = 0; kx < 7; ++kx) {
-                    const int xx = x + kx - 3;
-                    if (xx < 0 || xx >= p.W) continue;
-                    const float* mp = p.maps + (((size_t)n * p.H + yy) * p.W + xx) * 2;
-                    acc += w[ky * 7 + kx] * mp[0] + w[49 + ky * 7 + kx] * mp[1];
-                }
+        const int pix = (int)(idx - (long long)n * HW);
+        const int y = pix / p.W, x = pix - y * p.W;
+        for (int t = c8; t < 49; t += G) {
+            const int ky = t / 7, kx = t - ky * 7;
+            const int yy = y + ky - 3, xx = x + kx - 3;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+                const float2 mp = *reinterpret_cast<const float2*>(p.maps + (((size_t)n * p.H + yy) * p.W + xx) * 2);
+                part += w[t] * mp.x + w[49 + t] * mp.y;
             }
-            sas[pl] = sigmoidf(acc);
         }
     }
+    sas[tid] = part;
+    __syncthreads();
+    float sa_sum = 0.f;
+    if (live)
+        for (int j = 0; j < G; ++j) sa_sum += sas[pl * G + j];
+    __syncthreads();
+    if (live && c8 == 0) sas[pl] = sigmoidf(sa_sum);
     __syncthreads();
     if (!live) return;
     const float sa = sas[pl];
