@@ -1,0 +1,45 @@
+"""Toolchain guard (no GPU needed: hipcc cross-compiles): every MFMA kernel is compiled to gfx950 ISA and
+scanned for VALU reads of an MFMA result with too few wait states, including across branches — the defect
+ROCm 7.2's hipcc showed on `if (relu)` behind an accumulator (see sb.h relu_opt)."""
+import glob
+import importlib.util
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "esa-pose-estimation_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+spec = importlib.util.spec_from_file_location("isa_hazard_check", os.path.join(ROOT, "tools", "isa_hazard_check.py"))
+chk = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(chk)
+
+MFMA_SOURCES = sorted(f for f in glob.glob(os.path.join(CSRC, "*.hip")) if "mfma_f32" in open(f).read())
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src", MFMA_SOURCES, ids=[os.path.basename(s) for s in MFMA_SOURCES])
+def test_no_unpadded_mfma_result_reads(src, tmp_path):
+    out = tmp_path / (os.path.basename(src) + ".s")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                        "-S", "--cuda-device-only", "-o", str(out), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    found = chk.scan(str(out))
+    assert not found, found[:5]
+
+
+def test_scanner_sees_a_known_bad_sequence(tmp_path):
+    bad = tmp_path / "bad.s"
+    bad.write_text("\n".join([
+        "\tv_mfma_f32_16x16x32_bf16 v[54:57], v[54:57], v[30:33], v[50:53]",
+        "\ts_cbranch_vccz .LBB2_21",
+        "\ts_nop 6",
+        "\tv_max_i32_e32 v54, 0, v54",
+        ".LBB2_21:",
+        "\tv_cvt_pk_bf16_f32 v52, v54, v55",
+        "\ts_endpgm", ""]))
+    found = chk.scan(str(bad))
+    assert len(found) == 1 and found[0][1] < 7
