@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 in miniature: synthetic SPEED-shaped frames -> crops -> HRNet -> keypoints -> host PnP -> CSV.
+
+    python tools/e2e_submission.py --images 1024 --batch 32 [--variant seg_hrnet3] [--out DIR]
+
+Frames are random 1200x1920 uint8 images uploaded from pinned host memory batch by batch (so the GPU stage below
+includes the PCIe copy), detector boxes are random squares; the weights are the seed-reproducible random set, so the
+poses are meaningless — the run measures the plumbing and the stage rates:
+  gpu stage : H2D frames + crop/resize/normalise + forward + arg-max/refine + D2H of [N,K,3]
+  host stage: top-k, back-projection, EPnP + RANSAC + weighted LM, quaternion, CSV row   (numpy, one core)
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from esa_pose_estimation_amd import config, crops, inference, pipeline, pnp, synth  # noqa: E402
+import esa_pose_estimation_amd as pkg  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--images", type=int, default=1024)
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--variant", default="seg_hrnet2", choices=["seg_hrnet2", "seg_hrnet", "seg_hrnet3"])
+ap.add_argument("--scale", type=int, default=256)
+ap.add_argument("--out", default="gpurun_out")
+a = ap.parse_args()
+
+mod = getattr(__import__("esa_pose_estimation_amd." + a.variant), a.variant)
+net = mod.get_seg_model(config.make_config())
+net.load_state_dict(synth.make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=0))
+net = net.cuda().eval()
+K3 = net.num_keypoints
+kp3d = synth.uniform("e2e_kp3d", 1, (K3, 3), -0.6, 0.6).astype(np.float64)
+Kcam = np.array([[3003.41297, 0.0, 960.0], [0.0, 3003.41297, 600.0], [0.0, 0.0, 1.0]])
+
+rng = np.random.default_rng(0)
+nb = (a.images + a.batch - 1) // a.batch
+pin = torch.empty((a.batch, 1200, 1920), dtype=torch.uint8).pin_memory()
+pin.numpy()[:] = rng.integers(0, 256, size=(a.batch, 1200, 1920), dtype=np.uint8)     # one pinned batch, re-used
+
+
+def boxes(n):
+    c = rng.uniform([300, 250], [1620, 950], size=(n, 2))
+    s = rng.uniform(120, 500, size=(n, 1))
+    return np.concatenate([c - s / 2, c + s / 2], 1).astype(int).tolist()
+
+
+writer = pipeline.SubmissionWriter()
+t_gpu = t_host = 0.0
+kps, metas = [], []
+with torch.no_grad():
+    for b in range(nb + 1):                     # first batch = warm-up (weights fold/upload, workspace)
+        n = min(a.batch, a.images - max(b - 1, 0) * a.batch) if b else a.batch
+        bb = boxes(n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frames = pin[:n].cuda(non_blocking=True)
+        x, bx, rates = crops.crop_batch(frames, bb, a.scale)
+        kp = inference.heatmaps_to_keypoints(net(x)).cpu().numpy()
+        dt = time.perf_counter() - t0
+        if b:
+            t_gpu += dt
+            kps.append(kp)
+            metas.append((bx, rates))
+done = 0
+t0 = time.perf_counter()
+for kp, (bx, rates) in zip(kps, metas):
+    for i in range(len(bx)):
+        q, t, _ = pnp.keypoints_to_pose(kp[i], kp3d, Kcam, (bx[i][0], bx[i][1]), rates[i], thresh=0.0,
+                                        min_k=min(24, K3))
+        writer.append_test(f"img{done:06d}.jpg", q, t)
+        done += 1
+t_host = time.perf_counter() - t0
+os.makedirs(a.out, exist_ok=True)
+path = writer.export(out_dir=a.out, suffix="e2e")
+print(f"{a.variant}: {done} images, batch {a.batch}: gpu stage {done / t_gpu:.0f} images/s "
+      f"({t_gpu / nb * 1e3:.2f} ms per batch incl. {a.batch * 2.3:.0f} MB H2D), "
+      f"host PnP stage {done / t_host:.0f} images/s on one core; CSV: {path}")
