@@ -5,7 +5,8 @@
 
 Frames are random 1200x1920 uint8 images uploaded from pinned host memory batch by batch (so the GPU stage below
 includes the PCIe copy), detector boxes are random squares; the weights are the seed-reproducible random set, so the
-poses are meaningless — the run measures the plumbing and the stage rates:
+network's own keypoints are noise — the run measures the plumbing and the stage rates (the host stage by default on
+keypoints of random true poses, see --net-keypoints):
   gpu stage : H2D frames + crop/resize/normalise + forward + arg-max/refine + D2H of [N,K,3]
   host stage: top-k, back-projection, EPnP + RANSAC + weighted LM, quaternion, CSV row   (numpy, one core)
 """
@@ -27,6 +28,10 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--variant", default="seg_hrnet2", choices=["seg_hrnet2", "seg_hrnet", "seg_hrnet3"])
 ap.add_argument("--scale", type=int, default=256)
 ap.add_argument("--out", default="gpurun_out")
+ap.add_argument("--workers", type=int, default=0, help="processes for the host PnP stage (0 = in-process)")
+ap.add_argument("--net-keypoints", action="store_true",
+                help="solve poses from the (random-weight) network's keypoints: RANSAC never finds a consensus, i.e. the "
+                     "worst case of the host stage; default: keypoints of random true poses projected into the crop + 0.5 px noise")
 a = ap.parse_args()
 
 mod = getattr(__import__("esa_pose_estimation_amd." + a.variant), a.variant)
@@ -64,19 +69,29 @@ with torch.no_grad():
         dt = time.perf_counter() - t0
         if b:
             t_gpu += dt
+            if not a.net_keypoints:             # what a trained network would hand over: projections of a true pose
+                for i in range(n):
+                    R = pnp.rodrigues(rng.uniform(-1.0, 1.0, 3))
+                    tv = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(5.0, 12.0)])
+                    p2 = pnp.project(kp3d, R, tv, Kcam) + rng.normal(0, 0.5, (K3, 2))
+                    kp[i, :, :2] = (p2 - np.array([bx[i][0], bx[i][1]])) * rates[i]
+                    kp[i, :, 2] = rng.uniform(0.5, 1.0, K3)
             kps.append(kp)
             metas.append((bx, rates))
 done = 0
+pool = pipeline.pose_pool(a.workers) if a.workers > 1 else None
+if pool is not None:                              # spawn the workers outside the timed region
+    list(pool.map(int, range(a.workers)))
 t0 = time.perf_counter()
 for kp, (bx, rates) in zip(kps, metas):
-    for i in range(len(bx)):
-        q, t, _ = pnp.keypoints_to_pose(kp[i], kp3d, Kcam, (bx[i][0], bx[i][1]), rates[i], thresh=0.0,
-                                        min_k=min(24, K3))
+    for q, t in pipeline.poses_from_keypoints(kp, bx, rates, kp3d, Kcam, thresh=0.0, min_k=min(24, K3), pool=pool):
         writer.append_test(f"img{done:06d}.jpg", q, t)
         done += 1
 t_host = time.perf_counter() - t0
+if pool is not None:
+    pool.shutdown()
 os.makedirs(a.out, exist_ok=True)
 path = writer.export(out_dir=a.out, suffix="e2e")
 print(f"{a.variant}: {done} images, batch {a.batch}: gpu stage {done / t_gpu:.0f} images/s "
       f"({t_gpu / nb * 1e3:.2f} ms per batch incl. {a.batch * 2.3:.0f} MB H2D), "
-      f"host PnP stage {done / t_host:.0f} images/s on one core; CSV: {path}")
+      f"host PnP stage {done / t_host:.0f} images/s on {max(a.workers, 1)} process(es); CSV: {path}")
