@@ -56,6 +56,8 @@ _SIGS = {
     "esahrnet_keypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "esahrnet_crops": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                  C.c_void_p, C.c_void_p]),
+    "esahrnet_pnp_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "esahrnet_flops_per_crop": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "esahrnet_launch_count": (C.c_int, [C.c_void_p]),
     "esahrnet_op_desc_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(OpDesc)]),

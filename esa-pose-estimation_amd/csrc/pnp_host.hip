@@ -1,0 +1,609 @@
+// pnp_host.hip — the host pose solve behind the GPU path, in C++ (no device code in this file).
+//
+// Replaces (reference): pnp.py:46-90 (cv2.solvePnPRansac, SOLVEPNP_EPNP, reprojectionError 5 px, + Rodrigues),
+// cpnp.cpnp_m (val.py:194-209; Ceres refinement with peak-weighted residuals, model:
+// lib/utils/extend_utils/src/uncertainty_pnp.cpp:7-92), the top-k selection and crop -> image mapping of
+// val.py:172-180 and the [w,x,y,z] quaternion of val.py:221-224 — for a whole batch of keypoint rows.
+//
+// It is a line-by-line native restatement of esa-pose-estimation_amd/pnp.py (which is the oracle for it:
+// tests/test_pnp_native.py compares poses and inlier sets); like that module it restates the PUBLISHED
+// algorithms (EPnP, Lepetit et al. IJCV 2009; RANSAC with OpenCV's documented defaults; LM on angle-axis + t)
+// and its parity against OpenCV / the cpnp binary is UNPINNED (neither is available).
+// Dense linear algebra is hand-rolled for the tiny sizes involved (cyclic Jacobi for the symmetric 3x3 /
+// 4x4 / 12x12 eigenproblems, Householder QR least squares, Gaussian elimination).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "../../include/esahrnet.h"
+
+namespace {
+
+typedef double Mat3[3][3];
+
+// ---- splitmix64 stream: the same sampler as pnp.py:_sample (RANSAC minimal sets) -------------------
+struct SplitMix {
+    uint64_t s;
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+};
+// m distinct indices out of n by a partial Fisher-Yates shuffle
+void sample(SplitMix& g, int n, int m, int* idx) {
+    int perm[64];
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    for (int i = 0; i < m; ++i) {
+        const int j = i + (int)(g.next() % (uint64_t)(n - i));
+        std::swap(perm[i], perm[j]);
+        idx[i] = perm[i];
+    }
+}
+
+// ---- small dense helpers -------------------------------------------------------------------------------
+// symmetric eigen-decomposition by cyclic Jacobi: a (n x n, row major, destroyed) -> eigenvalues ascending in w,
+// eigenvectors in the COLUMNS of v (like numpy.linalg.eigh)
+void eigh(double* a, int n, double* w, double* v) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) v[i * n + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) {
+            diag += a[i * n + i] * a[i * n + i];
+            for (int j = i + 1; j < n; ++j) off += a[i * n + j] * a[i * n + j];
+        }
+        if (off <= 1e-30 * (diag + 1e-300)) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[p * n + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = c * akp - s * akq;
+                    a[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = c * apk - s * aqk;
+                    a[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = v[k * n + p], vkq = v[k * n + q];
+                    v[k * n + p] = c * vkp - s * vkq;
+                    v[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int order[16];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order, order + n, [&](int x, int y) { return a[x * n + x] < a[y * n + y]; });
+    double vt[16 * 16];
+    std::memcpy(vt, v, sizeof(double) * n * n);
+    for (int j = 0; j < n; ++j) {
+        w[j] = a[order[j] * n + order[j]];
+        for (int i = 0; i < n; ++i) v[i * n + j] = vt[i * n + order[j]];
+    }
+}
+
+// least squares min |A x - b| for an m x n system (m >= n, n <= 6) by Householder QR; columns whose pivot
+// collapses get x = 0 (numpy's lstsq returns the minimum-norm solution there; the callers' systems are full rank
+// except in degenerate minimal sets, which RANSAC discards by their reprojection error)
+void lstsq(const double* A, int m, int n, const double* b, double* x) {
+    double a[12 * 6], r[12];
+    for (int i = 0; i < m; ++i) {
+        for (int j = 0; j < n; ++j) a[i * n + j] = A[i * n + j];
+        r[i] = b[i];
+    }
+    bool dead[6] = {false, false, false, false, false, false};
+    double scale = 0.0;
+    for (int i = 0; i < m * n; ++i) scale = std::max(scale, std::fabs(a[i]));
+    for (int k = 0; k < n; ++k) {
+        double nrm = 0.0;
+        for (int i = k; i < m; ++i) nrm += a[i * n + k] * a[i * n + k];
+        nrm = std::sqrt(nrm);
+        if (nrm <= 1e-13 * scale) { dead[k] = true; continue; }
+        const double alpha = a[k * n + k] > 0 ? -nrm : nrm;
+        double vk[12];
+        for (int i = k; i < m; ++i) vk[i] = a[i * n + k];
+        vk[k] -= alpha;
+        double vn = 0.0;
+        for (int i = k; i < m; ++i) vn += vk[i] * vk[i];
+        if (vn > 0) {
+            for (int j = k; j < n; ++j) {
+                double d = 0.0;
+                for (int i = k; i < m; ++i) d += vk[i] * a[i * n + j];
+                d = 2.0 * d / vn;
+                for (int i = k; i < m; ++i) a[i * n + j] -= d * vk[i];
+            }
+            double d = 0.0;
+            for (int i = k; i < m; ++i) d += vk[i] * r[i];
+            d = 2.0 * d / vn;
+            for (int i = k; i < m; ++i) r[i] -= d * vk[i];
+        }
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        if (dead[k]) { x[k] = 0.0; continue; }
+        double s = r[k];
+        for (int j = k + 1; j < n; ++j) s -= a[k * n + j] * x[j];
+        x[k] = s / a[k * n + k];
+    }
+}
+
+// solve A x = b (n x n, n <= 6) by Gaussian elimination with partial pivoting; false if singular
+bool solve(const double* A, int n, const double* b, double* x) {
+    double a[6 * 7];
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) a[i * (n + 1) + j] = A[i * n + j];
+        a[i * (n + 1) + n] = b[i];
+    }
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(a[i * (n + 1) + k]) > std::fabs(a[piv * (n + 1) + k])) piv = i;
+        if (std::fabs(a[piv * (n + 1) + k]) < 1e-300) return false;
+        if (piv != k)
+            for (int j = 0; j <= n; ++j) std::swap(a[k * (n + 1) + j], a[piv * (n + 1) + j]);
+        for (int i = k + 1; i < n; ++i) {
+            const double f = a[i * (n + 1) + k] / a[k * (n + 1) + k];
+            for (int j = k; j <= n; ++j) a[i * (n + 1) + j] -= f * a[k * (n + 1) + j];
+        }
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        double s = a[k * (n + 1) + n];
+        for (int j = k + 1; j < n; ++j) s -= a[k * (n + 1) + j] * x[j];
+        x[k] = s / a[k * (n + 1) + k];
+    }
+    for (int i = 0; i < n; ++i)
+        if (!std::isfinite(x[i])) return false;
+    return true;
+}
+
+// ---- rotations (pnp.py: rodrigues, rodrigues_inv, rotation_to_quat_wxyz) ------------------------------
+void rodrigues(const double r[3], Mat3 R) {
+    const double th = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    double k[3] = {r[0], r[1], r[2]};
+    double a = 1.0, bq = 0.0;                     // R = I + a*K + b*K^2
+    if (th >= 1e-12) {
+        for (double& v : k) v /= th;
+        a = std::sin(th);
+        bq = 1.0 - std::cos(th);
+    }
+    const double K[3][3] = {{0, -k[2], k[1]}, {k[2], 0, -k[0]}, {-k[1], k[0], 0}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double kk = 0.0;
+            for (int l = 0; l < 3; ++l) kk += K[i][l] * K[l][j];
+            R[i][j] = (i == j ? 1.0 : 0.0) + a * K[i][j] + bq * kk;
+        }
+}
+
+void rodrigues_inv(const Mat3 R, double r[3]) {
+    double c = (R[0][0] + R[1][1] + R[2][2] - 1.0) / 2.0;
+    c = std::min(1.0, std::max(-1.0, c));
+    const double th = std::acos(c);
+    const double w[3] = {R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1]};
+    if (th < 1e-10) {
+        for (int i = 0; i < 3; ++i) r[i] = 0.5 * w[i];
+        return;
+    }
+    if (M_PI - th < 1e-6) {                       // near pi: take the axis from the symmetric part
+        double A[3][3], d[3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) A[i][j] = (R[i][j] + (i == j ? 1.0 : 0.0)) / 2.0;
+        for (int i = 0; i < 3; ++i) d[i] = std::sqrt(std::max(A[i][i], 0.0));
+        int im = 0;
+        for (int i = 1; i < 3; ++i)
+            if (d[i] > d[im]) im = i;
+        double k[3];
+        for (int j = 0; j < 3; ++j) k[j] = A[im][j] / std::max(d[im], 1e-12);
+        const double kn = std::sqrt(k[0] * k[0] + k[1] * k[1] + k[2] * k[2]);
+        for (double& v : k) v /= kn;
+        if (k[0] * w[0] + k[1] * w[1] + k[2] * w[2] < 0)
+            for (double& v : k) v = -v;
+        for (int i = 0; i < 3; ++i) r[i] = th * k[i];
+        return;
+    }
+    const double f = th / (2.0 * std::sin(th));
+    for (int i = 0; i < 3; ++i) r[i] = f * w[i];
+}
+
+void quat_wxyz(const Mat3 R, double q[4]) {
+    const double t = R[0][0] + R[1][1] + R[2][2];
+    if (t > 0) {
+        const double s = std::sqrt(t + 1.0) * 2;
+        q[0] = 0.25 * s; q[1] = (R[2][1] - R[1][2]) / s; q[2] = (R[0][2] - R[2][0]) / s; q[3] = (R[1][0] - R[0][1]) / s;
+    } else {
+        int i = 0;
+        if (R[1][1] > R[i][i]) i = 1;
+        if (R[2][2] > R[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        const double s = std::sqrt(1.0 + R[i][i] - R[j][j] - R[k][k]) * 2;
+        q[0] = (R[k][j] - R[j][k]) / s;
+        q[1 + i] = 0.25 * s;
+        q[1 + j] = (R[j][i] + R[i][j]) / s;
+        q[1 + k] = (R[k][i] + R[i][k]) / s;
+    }
+    const double nq = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= nq;
+}
+
+struct Cam {
+    double fx, fy, cx, cy;
+};
+
+inline void project1(const double p[3], const Mat3 R, const double t[3], const Cam& K, double uv[2]) {
+    double pc[3];
+    for (int i = 0; i < 3; ++i) pc[i] = R[i][0] * p[0] + R[i][1] * p[1] + R[i][2] * p[2] + t[i];
+    uv[0] = K.fx * pc[0] / pc[2] + K.cx;
+    uv[1] = K.fy * pc[1] / pc[2] + K.cy;
+}
+
+// ---- EPnP (pnp.py: epnp and helpers) ------------------------------------------------------------------------
+const int PAIRS[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+
+void betas_quadratic(const double b[4], double o[10]) {
+    o[0] = b[0] * b[0]; o[1] = b[0] * b[1]; o[2] = b[1] * b[1]; o[3] = b[0] * b[2]; o[4] = b[1] * b[2];
+    o[5] = b[2] * b[2]; o[6] = b[0] * b[3]; o[7] = b[1] * b[3]; o[8] = b[2] * b[3]; o[9] = b[3] * b[3];
+}
+
+void gauss_newton(const double L[6][10], const double rho[6], double b[4]) {
+    for (int it = 0; it < 5; ++it) {
+        double J[6 * 4], r[6], bq[10], d[4];
+        betas_quadratic(b, bq);
+        for (int i = 0; i < 6; ++i) {
+            J[i * 4 + 0] = 2 * b[0] * L[i][0] + b[1] * L[i][1] + b[2] * L[i][3] + b[3] * L[i][6];
+            J[i * 4 + 1] = b[0] * L[i][1] + 2 * b[1] * L[i][2] + b[2] * L[i][4] + b[3] * L[i][7];
+            J[i * 4 + 2] = b[0] * L[i][3] + b[1] * L[i][4] + 2 * b[2] * L[i][5] + b[3] * L[i][8];
+            J[i * 4 + 3] = b[0] * L[i][6] + b[1] * L[i][7] + b[2] * L[i][8] + 2 * b[3] * L[i][9];
+            double s = 0.0;
+            for (int k = 0; k < 10; ++k) s += L[i][k] * bq[k];
+            r[i] = rho[i] - s;
+        }
+        lstsq(J, 6, 4, r, d);
+        for (int k = 0; k < 4; ++k) b[k] += d[k];
+    }
+}
+
+// absolute orientation pw -> pc by Horn's quaternion method (the proper rotation Kabsch + det correction gives)
+void pose_from_betas(const double b[4], const double* V /*12x4*/, const double* alphas /*n x 4*/, const double* pw, int n,
+                     Mat3 R, double t[3]) {
+    double cc[4][3];
+    for (int i = 0; i < 12; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += V[i * 4 + k] * b[k];
+        cc[i / 3][i % 3] = s;
+    }
+    std::vector<double> pc(3 * n);
+    double zmean = 0.0;
+    for (int i = 0; i < n; ++i) {
+        for (int d = 0; d < 3; ++d) {
+            double s = 0.0;
+            for (int j = 0; j < 4; ++j) s += alphas[i * 4 + j] * cc[j][d];
+            pc[i * 3 + d] = s;
+        }
+        zmean += pc[i * 3 + 2];
+    }
+    if (zmean / n < 0)
+        for (double& v : pc) v = -v;
+    double mw[3] = {0, 0, 0}, mc[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) { mw[d] += pw[i * 3 + d] / n; mc[d] += pc[i * 3 + d] / n; }
+    double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};       // S[a][b] = sum (pw-mw)[a] * (pc-mc)[b]
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) S[a][c] += (pw[i * 3 + a] - mw[a]) * (pc[i * 3 + c] - mc[c]);
+    double N[16] = {
+        S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0],
+        S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2],
+        S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1],
+        S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]};
+    double w4[4], v4[16];
+    eigh(N, 4, w4, v4);
+    const double qw = v4[0 * 4 + 3], qx = v4[1 * 4 + 3], qy = v4[2 * 4 + 3], qz = v4[3 * 4 + 3];   // largest eigenvalue
+    R[0][0] = 1 - 2 * (qy * qy + qz * qz); R[0][1] = 2 * (qx * qy - qz * qw); R[0][2] = 2 * (qx * qz + qy * qw);
+    R[1][0] = 2 * (qx * qy + qz * qw); R[1][1] = 1 - 2 * (qx * qx + qz * qz); R[1][2] = 2 * (qy * qz - qx * qw);
+    R[2][0] = 2 * (qx * qz - qy * qw); R[2][1] = 2 * (qy * qz + qx * qw); R[2][2] = 1 - 2 * (qx * qx + qy * qy);
+    for (int d = 0; d < 3; ++d) t[d] = mc[d] - (R[d][0] * mw[0] + R[d][1] * mw[1] + R[d][2] * mw[2]);
+}
+
+// EPnP for n >= 4 points; false when no candidate gives a finite error
+bool epnp(const double* pw, const double* uv, int n, const Cam& K, Mat3 Rb, double tb[3]) {
+    // control points: centroid + principal directions
+    double c0[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) c0[d] += pw[i * 3 + d] / n;
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) C[a * 3 + c] += (pw[i * 3 + a] - c0[a]) * (pw[i * 3 + c] - c0[c]);
+    double ev[3], evec[9];
+    eigh(C, 3, ev, evec);
+    double cws[4][3];
+    for (int d = 0; d < 3; ++d) cws[0][d] = c0[d];
+    for (int k = 0; k < 3; ++k) {
+        const double s = std::sqrt(std::max(ev[k], 1e-18) / n);
+        for (int d = 0; d < 3; ++d) cws[k + 1][d] = c0[d] + s * evec[d * 3 + k];
+    }
+    // barycentric coordinates
+    double A[9];
+    for (int d = 0; d < 3; ++d)
+        for (int k = 0; k < 3; ++k) A[d * 3 + k] = cws[k + 1][d] - cws[0][d];
+    std::vector<double> alphas(4 * n);
+    for (int i = 0; i < n; ++i) {
+        double rhs[3] = {pw[i * 3] - cws[0][0], pw[i * 3 + 1] - cws[0][1], pw[i * 3 + 2] - cws[0][2]}, a3[3];
+        if (!solve(A, 3, rhs, a3)) return false;
+        alphas[i * 4 + 0] = 1.0 - a3[0] - a3[1] - a3[2];
+        for (int k = 0; k < 3; ++k) alphas[i * 4 + 1 + k] = a3[k];
+    }
+    // M^T M (12 x 12) accumulated row by row
+    double MtM[144];
+    std::memset(MtM, 0, sizeof MtM);
+    for (int i = 0; i < n; ++i) {
+        double r0[12], r1[12];
+        for (int j = 0; j < 4; ++j) {
+            const double a = alphas[i * 4 + j];
+            r0[3 * j + 0] = a * K.fx; r0[3 * j + 1] = 0.0; r0[3 * j + 2] = a * (K.cx - uv[i * 2 + 0]);
+            r1[3 * j + 0] = 0.0; r1[3 * j + 1] = a * K.fy; r1[3 * j + 2] = a * (K.cy - uv[i * 2 + 1]);
+        }
+        for (int p = 0; p < 12; ++p)
+            for (int q = 0; q < 12; ++q) MtM[p * 12 + q] += r0[p] * r0[q] + r1[p] * r1[q];
+    }
+    double w12[12], v12[144];
+    eigh(MtM, 12, w12, v12);
+    double V[12 * 4];
+    for (int i = 0; i < 12; ++i)
+        for (int k = 0; k < 4; ++k) V[i * 4 + k] = v12[i * 12 + k];
+    double dv[4][6][3];
+    for (int k = 0; k < 4; ++k)
+        for (int pi = 0; pi < 6; ++pi)
+            for (int d = 0; d < 3; ++d) dv[k][pi][d] = V[(3 * PAIRS[pi][0] + d) * 4 + k] - V[(3 * PAIRS[pi][1] + d) * 4 + k];
+    double L[6][10], rho[6];
+    auto dot = [](const double* x, const double* y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+    for (int pi = 0; pi < 6; ++pi) {
+        const double *d0 = dv[0][pi], *d1 = dv[1][pi], *d2 = dv[2][pi], *d3 = dv[3][pi];
+        L[pi][0] = dot(d0, d0); L[pi][1] = 2 * dot(d0, d1); L[pi][2] = dot(d1, d1); L[pi][3] = 2 * dot(d0, d2);
+        L[pi][4] = 2 * dot(d1, d2); L[pi][5] = dot(d2, d2); L[pi][6] = 2 * dot(d0, d3); L[pi][7] = 2 * dot(d1, d3);
+        L[pi][8] = 2 * dot(d2, d3); L[pi][9] = dot(d3, d3);
+        rho[pi] = 0.0;
+        for (int d = 0; d < 3; ++d) {
+            const double e = cws[PAIRS[pi][0]][d] - cws[PAIRS[pi][1]][d];
+            rho[pi] += e * e;
+        }
+    }
+    double cands[3][4];
+    {   // N = 1 .. 3 linearisations
+        double Ls[6 * 5], sol[5];
+        const int c1[4] = {0, 1, 3, 6};
+        for (int i = 0; i < 6; ++i)
+            for (int k = 0; k < 4; ++k) Ls[i * 4 + k] = L[i][c1[k]];
+        lstsq(Ls, 6, 4, rho, sol);
+        if (sol[0] < 0)
+            for (int k = 0; k < 4; ++k) sol[k] = -sol[k];
+        const double b1 = std::sqrt(std::max(sol[0], 1e-18));
+        cands[0][0] = b1; cands[0][1] = sol[1] / b1; cands[0][2] = sol[2] / b1; cands[0][3] = sol[3] / b1;
+
+        for (int i = 0; i < 6; ++i)
+            for (int k = 0; k < 3; ++k) Ls[i * 3 + k] = L[i][k];
+        lstsq(Ls, 6, 3, rho, sol);
+        double* b = cands[1];
+        b[0] = b[1] = b[2] = b[3] = 0.0;
+        if (sol[0] < 0) { b[0] = std::sqrt(-sol[0]); b[1] = std::sqrt(std::max(-sol[2], 0.0)); }
+        else { b[0] = std::sqrt(sol[0]); b[1] = std::sqrt(std::max(sol[2], 0.0)); }
+        if (sol[1] < 0) b[0] = -b[0];
+
+        for (int i = 0; i < 6; ++i)
+            for (int k = 0; k < 5; ++k) Ls[i * 5 + k] = L[i][k];
+        lstsq(Ls, 6, 5, rho, sol);
+        b = cands[2];
+        b[0] = b[1] = b[2] = b[3] = 0.0;
+        if (sol[0] < 0) { b[0] = std::sqrt(-sol[0]); b[1] = std::sqrt(std::max(-sol[2], 0.0)); }
+        else { b[0] = std::sqrt(sol[0]); b[1] = std::sqrt(std::max(sol[2], 0.0)); }
+        if (sol[1] < 0) b[0] = -b[0];
+        b[2] = std::fabs(b[0]) > 1e-18 ? sol[3] / b[0] : 0.0;
+    }
+    bool have = false;
+    double best = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        double b[4] = {cands[c][0], cands[c][1], cands[c][2], cands[c][3]};
+        gauss_newton(L, rho, b);
+        Mat3 R;
+        double t[3];
+        pose_from_betas(b, V, alphas.data(), pw, n, R, t);
+        double err = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double p[2];
+            project1(pw + i * 3, R, t, K, p);
+            err += (p[0] - uv[i * 2]) * (p[0] - uv[i * 2]) + (p[1] - uv[i * 2 + 1]) * (p[1] - uv[i * 2 + 1]);
+        }
+        if (std::isfinite(err) && (!have || err < best)) {
+            have = true;
+            best = err;
+            std::memcpy(Rb, R, sizeof(Mat3));
+            std::memcpy(tb, t, 3 * sizeof(double));
+        }
+    }
+    return have;
+}
+
+// ---- RANSAC (pnp.py: solve_pnp_ransac) ------------------------------------------------------------------------
+bool ransac(const double* p3d, const double* p2d, int n, const Cam& K, Mat3 R, double t[3], unsigned char* mask) {
+    const double reproj = 5.0, confidence = 0.99;
+    const int iters = 100, m = std::min(5, n);
+    SplitMix g{0};
+    std::vector<unsigned char> cur(n), bestm(n, 0);
+    int best_cnt = -1, niter = iters, it = 0;
+    while (it < niter) {
+        ++it;
+        int idx[8];
+        sample(g, n, m, idx);
+        double sw[15], su[10];
+        for (int i = 0; i < m; ++i) {
+            std::memcpy(sw + i * 3, p3d + idx[i] * 3, 3 * sizeof(double));
+            std::memcpy(su + i * 2, p2d + idx[i] * 2, 2 * sizeof(double));
+        }
+        Mat3 Rh;
+        double th[3];
+        if (!epnp(sw, su, m, K, Rh, th)) continue;
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            double p[2];
+            project1(p3d + i * 3, Rh, th, K, p);
+            const double e = std::sqrt((p[0] - p2d[i * 2]) * (p[0] - p2d[i * 2]) + (p[1] - p2d[i * 2 + 1]) * (p[1] - p2d[i * 2 + 1]));
+            cur[i] = e < reproj;                 // NaN compares false, like numpy
+            cnt += cur[i];
+        }
+        if (cnt > best_cnt) {
+            best_cnt = cnt;
+            bestm = cur;
+            const double w = std::max((double)cnt / n, 1e-9);
+            const double denom = std::log(std::max(1.0 - std::pow(w, m), 1e-12));
+            niter = denom < 0 ? std::min(iters, (int)std::ceil(std::log(1.0 - confidence) / denom)) : iters;
+        }
+    }
+    if (best_cnt < 4) std::fill(bestm.begin(), bestm.end(), 1);
+    std::vector<double> iw, iu;
+    for (int i = 0; i < n; ++i)
+        if (bestm[i]) {
+            iw.insert(iw.end(), p3d + i * 3, p3d + i * 3 + 3);
+            iu.insert(iu.end(), p2d + i * 2, p2d + i * 2 + 2);
+        }
+    if (mask) std::memcpy(mask, bestm.data(), n);
+    return epnp(iw.data(), iu.data(), (int)(iw.size() / 3), K, R, t);
+}
+
+// ---- weighted LM refinement (pnp.py: cpnp_m) ------------------------------------------------------------------
+void cpnp(const double* p3d, const double* p2d, const double* wts, int n, const Cam& K, double x[6]) {
+    std::vector<double> r(2 * n), rn(2 * n), J(2 * n * 6);
+    auto residual = [&](const double* xx, std::vector<double>& out, Mat3 R) {
+        rodrigues(xx, R);
+        for (int i = 0; i < n; ++i) {
+            double p[2];
+            project1(p3d + i * 3, R, xx + 3, K, p);
+            out[2 * i] = wts[i] * (p[0] - p2d[i * 2]);
+            out[2 * i + 1] = wts[i] * (p[1] - p2d[i * 2 + 1]);
+        }
+    };
+    auto sq = [&](const std::vector<double>& v) { double s = 0.0; for (double e : v) s += e * e; return s; };
+    Mat3 R;
+    residual(x, r, R);
+    double cost = sq(r), lam = 1e-3;
+    for (int it = 0; it < 50; ++it) {
+        for (int i = 0; i < n; ++i) {
+            double rp[3], pc[3];
+            for (int d = 0; d < 3; ++d) {
+                rp[d] = R[d][0] * p3d[i * 3] + R[d][1] * p3d[i * 3 + 1] + R[d][2] * p3d[i * 3 + 2];
+                pc[d] = rp[d] + x[3 + d];
+            }
+            const double X = pc[0], Y = pc[1], Z = pc[2];
+            const double dpx[3] = {K.fx / Z, 0.0, -K.fx * X / (Z * Z)}, dpy[3] = {0.0, K.fy / Z, -K.fy * Y / (Z * Z)};
+            const double S[3][3] = {{0, rp[2], -rp[1]}, {-rp[2], 0, rp[0]}, {rp[1], -rp[0], 0}};      // -[rp]x
+            for (int c = 0; c < 3; ++c) {
+                J[(2 * i) * 6 + c] = wts[i] * (dpx[0] * S[0][c] + dpx[1] * S[1][c] + dpx[2] * S[2][c]);
+                J[(2 * i + 1) * 6 + c] = wts[i] * (dpy[0] * S[0][c] + dpy[1] * S[1][c] + dpy[2] * S[2][c]);
+                J[(2 * i) * 6 + 3 + c] = wts[i] * dpx[c];
+                J[(2 * i + 1) * 6 + 3 + c] = wts[i] * dpy[c];
+            }
+        }
+        double H[36], gvec[6];
+        for (int a = 0; a < 6; ++a) {
+            gvec[a] = 0.0;
+            for (int k = 0; k < 2 * n; ++k) gvec[a] += J[k * 6 + a] * r[k];
+            for (int c = 0; c < 6; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < 2 * n; ++k) s += J[k * 6 + a] * J[k * 6 + c];
+                H[a * 6 + c] = s;
+            }
+        }
+        bool improved = false, done = false;
+        for (int tr = 0; tr < 10; ++tr) {
+            double Hd[36], ng[6], d[6];
+            std::memcpy(Hd, H, sizeof H);
+            for (int a = 0; a < 6; ++a) { Hd[a * 6 + a] += lam * (H[a * 6 + a] + 1e-12); ng[a] = -gvec[a]; }
+            if (!solve(Hd, 6, ng, d)) { lam *= 10; continue; }
+            double xn[6];
+            Mat3 dR, Rn;
+            rodrigues(d, dR);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) Rn[i][j] = dR[i][0] * R[0][j] + dR[i][1] * R[1][j] + dR[i][2] * R[2][j];
+            rodrigues_inv(Rn, xn);
+            for (int c = 0; c < 3; ++c) xn[3 + c] = x[3 + c] + d[3 + c];
+            Mat3 Rr;
+            residual(xn, rn, Rr);
+            const double cn = sq(rn);
+            if (std::isfinite(cn) && cn < cost) {
+                std::memcpy(x, xn, sizeof xn);
+                r = rn;
+                std::memcpy(R, Rr, sizeof(Mat3));
+                lam = std::max(lam / 3, 1e-9);
+                improved = true;
+                done = cost - cn < 1e-14 * std::max(cost, 1e-30);
+                cost = cn;
+                break;
+            }
+            lam *= 4;
+        }
+        if (!improved || done) break;
+    }
+}
+
+// ---- one image: val.py:172-224 --------------------------------------------------------------------------------
+void pose_one(const float* kp, int k, const double* kp3d, const Cam& K, double x0, double y0, double rate, double thresh,
+              int min_k, double q[4], double t[3]) {
+    // top-k by peak (heapq.nlargest: descending, ties keep index order)
+    int large = 0;
+    for (int i = 0; i < k; ++i) large += (double)kp[i * 3 + 2] > thresh;
+    large = std::min(k, std::max(large, min_k));
+    std::vector<int> order(k);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kp[a * 3 + 2] > kp[b * 3 + 2]; });
+    std::vector<double> p3(3 * large), p2(2 * large), wv(large);
+    const double inv = 1.0 / rate;
+    for (int i = 0; i < large; ++i) {
+        const int j = order[i];
+        for (int d = 0; d < 3; ++d) p3[i * 3 + d] = kp3d[j * 3 + d];
+        p2[i * 2 + 0] = (double)kp[j * 3 + 0] * inv + x0;
+        p2[i * 2 + 1] = (double)kp[j * 3 + 1] * inv + y0;
+        wv[i] = (double)kp[j * 3 + 2];
+    }
+    Mat3 R;
+    double tt[3], cam[6];
+    if (large < 4 || !ransac(p3.data(), p2.data(), large, K, R, tt, nullptr)) {
+        q[0] = q[1] = q[2] = q[3] = t[0] = t[1] = t[2] = NAN;
+        return;
+    }
+    rodrigues_inv(R, cam);
+    for (int d = 0; d < 3; ++d) cam[3 + d] = tt[d];
+    cpnp(p3.data(), p2.data(), wv.data(), large, K, cam);
+    rodrigues(cam, R);
+    quat_wxyz(R, q);
+    for (int d = 0; d < 3; ++d) t[d] = cam[3 + d];
+}
+
+}  // namespace
+
+extern "C" int esahrnet_pnp_batch(const float* kp, int n, int k, const double* kp3d, const double* K9, const int* boxes_xy,
+                                  const double* rates, double thresh, int min_k, int threads, double* q_out,
+                                  double* t_out) {
+    if (!kp || !kp3d || !K9 || !boxes_xy || !rates || !q_out || !t_out || n < 0 || k < 1 || k > 64) return 1;
+    const Cam K{K9[0], K9[4], K9[2], K9[5]};
+    auto work = [&](int lo, int hi) {
+        for (int i = lo; i < hi; ++i)
+            pose_one(kp + (size_t)i * k * 3, k, kp3d, K, (double)boxes_xy[i * 2], (double)boxes_xy[i * 2 + 1], rates[i],
+                     thresh, min_k, q_out + (size_t)i * 4, t_out + (size_t)i * 3);
+    };
+    const int nt = std::max(1, std::min(threads, n));
+    if (nt == 1) { work(0, n); return 0; }
+    std::vector<std::thread> pool;
+    for (int w = 0; w < nt; ++w) pool.emplace_back(work, (int)((long long)n * w / nt), (int)((long long)n * (w + 1) / nt));
+    for (std::thread& th : pool) th.join();
+    return 0;
+}

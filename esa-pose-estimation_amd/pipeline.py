@@ -67,10 +67,15 @@ def _pose_job(args):
     return q, t
 
 
-def poses_from_keypoints(kp, boxes, rates, kp3d, K, thresh: float = 0.8, min_k: int = 24, pool=None):
+def poses_from_keypoints(kp, boxes, rates, kp3d, K, thresh: float = 0.8, min_k: int = 24, pool=None,
+                         native: bool = True, threads: int = 0):
     """Host stage of val.py:172-224 for a batch: kp [N,K,3] (numpy) -> list of (q [w,x,y,z], t).
-    `pool`: a concurrent.futures executor (e.g. `pose_pool(16)`) to spread the images over cores."""
+    native=True: the C++ solver of the library (`esahrnet_pnp_batch`, `threads` worker threads, ~100 us per image
+    and thread); native=False: the numpy restatement it is tested against (optionally over a process `pool`)."""
     K = np.asarray(K, np.float64)
+    if native:
+        q, t = pnp.keypoints_to_pose_batch(kp, kp3d, K, [(b[0], b[1]) for b in boxes], rates, thresh, min_k, threads)
+        return [(q[i], t[i]) for i in range(len(boxes))]
     jobs = [(kp[i], kp3d, K, (boxes[i][0], boxes[i][1]), rates[i], thresh, min_k) for i in range(len(boxes))]
     if pool is not None:
         return list(pool.map(_pose_job, jobs, chunksize=max(1, len(jobs) // 32)))
@@ -83,7 +88,7 @@ def pose_pool(workers: int):
 
 
 def estimate_poses(net, frames: torch.Tensor, bboxes, kp3d, K, scale: int = 256, thresh: float = 0.8,
-                   min_k: int = 24, distributed: bool = False, pool=None):
+                   min_k: int = 24, distributed: bool = False, pool=None, native: bool = True):
     """One batch of the val.py:136-233 loop.  frames uint8 cuda [N,H,W]; bboxes N x (x, y, x2, y2);
     kp3d [K3, 3] model keypoints; K camera matrix.  -> list of (q [w,x,y,z], t) per image."""
     x, boxes, rates = crops.crop_batch(frames, bboxes, scale)
@@ -93,7 +98,7 @@ def estimate_poses(net, frames: torch.Tensor, bboxes, kp3d, K, scale: int = 256,
         else:
             kp = inference.heatmaps_to_keypoints(net(x))
     kp = kp.cpu().numpy()                                   # the only device->host copy: N*K*3 floats
-    return poses_from_keypoints(kp, boxes, rates, kp3d, K, thresh, min_k, pool)
+    return poses_from_keypoints(kp, boxes, rates, kp3d, K, thresh, min_k, pool, native)
 
 
 def run_submission(net, batches, kp3d, K, writer: SubmissionWriter, real: bool = False, **kw):

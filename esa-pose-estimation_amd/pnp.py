@@ -210,6 +210,31 @@ def epnp(p3d, p2d, K):
     return best[1], best[2]
 
 
+_M64 = (1 << 64) - 1
+
+
+class _SplitMix:
+    """splitmix64 stream — the minimal-set sampler shared bit for bit with csrc/pnp_host.hip."""
+
+    def __init__(self, seed=0):
+        self.s = seed & _M64
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & _M64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        return z ^ (z >> 31)
+
+    def sample(self, n, m):
+        """m distinct indices out of n: partial Fisher-Yates shuffle."""
+        perm = list(range(n))
+        for i in range(m):
+            j = i + self.next() % (n - i)
+            perm[i], perm[j] = perm[j], perm[i]
+        return perm[:m]
+
+
 def solve_pnp_ransac(p3d, p2d, K, reproj_err=5.0, iters=100, confidence=0.99, seed=0):
     """RANSAC over 5-point EPnP models, inliers = reprojection error < reproj_err px, final EPnP on
     the inliers (cv2.solvePnPRansac(flags=SOLVEPNP_EPNP) semantics).  -> (R, t, inlier_mask)."""
@@ -219,12 +244,12 @@ def solve_pnp_ransac(p3d, p2d, K, reproj_err=5.0, iters=100, confidence=0.99, se
     if n < 4:
         raise ValueError("need at least 4 correspondences")
     m = min(5, n)
-    rng = np.random.default_rng(seed)
+    rng = _SplitMix(seed)
     best_mask, best_cnt, niter = None, -1, iters
     it = 0
     while it < niter:
         it += 1
-        idx = rng.choice(n, m, replace=False)
+        idx = rng.sample(n, m)
         try:
             R, t = epnp(p3d[idx], p2d[idx], K)
         except np.linalg.LinAlgError:
@@ -319,6 +344,31 @@ def speed_score(q_pred, t_pred, q_gt, t_gt):
     d = abs(float(np.dot(np.asarray(q_pred, np.float64), np.asarray(q_gt, np.float64))))
     sr = 2.0 * np.arccos(min(1.0, d))
     return st + sr, st, sr
+
+
+def keypoints_to_pose_batch(kp, kp3d, K, boxes_xy, rates, thresh=0.8, min_k=24, threads=0):
+    """The host stage for a whole batch in native code (csrc/pnp_host.hip, `esahrnet_pnp_batch`): kp [N,K,3]
+    f32 as the GPU path wrote it -> (q [N,4] = [w,x,y,z], t [N,3]); rows without a solution are NaN.
+    The same algorithm, step for step, as `keypoints_to_pose` below (which is its oracle)."""
+    import ctypes as C
+    import os
+    from . import _lib
+    kp = np.ascontiguousarray(kp, np.float32)
+    n, k = kp.shape[0], kp.shape[1]
+    kp3d = np.ascontiguousarray(kp3d, np.float64)
+    K9 = np.ascontiguousarray(K, np.float64).reshape(9)
+    bxy = np.ascontiguousarray(np.asarray(boxes_xy)[:, :2], np.int32)
+    rt = np.ascontiguousarray(rates, np.float64)
+    assert kp3d.shape == (k, 3) and bxy.shape == (n, 2) and rt.shape == (n,)
+    q = np.empty((n, 4), np.float64)
+    t = np.empty((n, 3), np.float64)
+    if threads <= 0:
+        threads = min(16, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else 4
+    _lib.check(_lib.lib().esahrnet_pnp_batch(kp.ctypes.data_as(C.c_void_p), n, k, kp3d.ctypes.data_as(C.c_void_p),
+                                             K9.ctypes.data_as(C.c_void_p), bxy.ctypes.data_as(C.c_void_p),
+                                             rt.ctypes.data_as(C.c_void_p), float(thresh), int(min_k), int(threads),
+                                             q.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p)))
+    return q, t
 
 
 def keypoints_to_pose(kp, kp3d, K, bbox_xy, rate, thresh=0.8, min_k=24):

@@ -109,6 +109,16 @@ int esahrnet_keypoints(const void* heat_dev, int n, int k, int height, int width
 int esahrnet_crops(const void* frames_dev, int n, int frame_h, int frame_w, const void* boxes_dev, int scale,
                    float mean, float stdv, void* out_dev, esahrnet_stream stream);
 
+/* Host pose solve behind the path, for a batch (pnp.py:46-90 + cpnp.cpnp_m of val.py:194-209 + val.py:172-180,
+ * 221-224): kp = host f32 [n][k][3] keypoint rows (x, y, peak) in crop coordinates as esahrnet_keypoints wrote
+ * them; kp3d = f64 [k][3] model points; K9 = f64 row-major camera matrix; boxes_xy = int32 [n][2] crop origins;
+ * rates = f64 [n] crop scale factors.  Per image: keypoints with peak > thresh (at least min_k, largest first),
+ * mapped back to image pixels, EPnP + RANSAC (5 px, 100 iterations, 0.99), peak-weighted LM refinement,
+ * -> q_out f64 [n][4] = [w, x, y, z], t_out f64 [n][3] (NaN when fewer than 4 keypoints or no solution).
+ * Pure host code, `threads` worker threads; needs no GPU.  Returns 0, or 1 on a bad argument. */
+int esahrnet_pnp_batch(const float* kp, int n, int k, const double* kp3d, const double* K9, const int* boxes_xy,
+                       const double* rates, double thresh, int min_k, int threads, double* q_out, double* t_out);
+
 /* ---- introspection / per-operator entry points (used by the parity tests) ------------- */
 
 /* Algorithmic (direct-convolution) FLOPs of one forward of one crop: 2 * MACs of every conv. */

@@ -8,7 +8,7 @@ includes the PCIe copy), detector boxes are random squares; the weights are the 
 network's own keypoints are noise — the run measures the plumbing and the stage rates (the host stage by default on
 keypoints of random true poses, see --net-keypoints):
   gpu stage : H2D frames + crop/resize/normalise + forward + arg-max/refine + D2H of [N,K,3]
-  host stage: top-k, back-projection, EPnP + RANSAC + weighted LM, quaternion, CSV row   (numpy, one core)
+  host stage: top-k, back-projection, EPnP + RANSAC + weighted LM, quaternion, CSV row   (native C++ by default)
 """
 import argparse
 import os
@@ -28,7 +28,9 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--variant", default="seg_hrnet2", choices=["seg_hrnet2", "seg_hrnet", "seg_hrnet3"])
 ap.add_argument("--scale", type=int, default=256)
 ap.add_argument("--out", default="gpurun_out")
-ap.add_argument("--workers", type=int, default=0, help="processes for the host PnP stage (0 = in-process)")
+ap.add_argument("--workers", type=int, default=0, help="numpy host stage: processes (0 = in-process)")
+ap.add_argument("--numpy-pnp", action="store_true", help="host stage by the numpy restatement instead of the native solver")
+ap.add_argument("--threads", type=int, default=0, help="native host stage: worker threads (0 = all allowed cores, max 16)")
 ap.add_argument("--net-keypoints", action="store_true",
                 help="solve poses from the (random-weight) network's keypoints: RANSAC never finds a consensus, i.e. the "
                      "worst case of the host stage; default: keypoints of random true poses projected into the crop + 0.5 px noise")
@@ -79,12 +81,14 @@ with torch.no_grad():
             kps.append(kp)
             metas.append((bx, rates))
 done = 0
-pool = pipeline.pose_pool(a.workers) if a.workers > 1 else None
+pool = pipeline.pose_pool(a.workers) if (a.workers > 1 and a.numpy_pnp) else None
+pipeline.poses_from_keypoints(kps[0][:1], metas[0][0][:1], metas[0][1][:1], kp3d, Kcam, 0.0, min(24, K3))   # warm the library
 if pool is not None:                              # spawn the workers outside the timed region
     list(pool.map(int, range(a.workers)))
 t0 = time.perf_counter()
 for kp, (bx, rates) in zip(kps, metas):
-    for q, t in pipeline.poses_from_keypoints(kp, bx, rates, kp3d, Kcam, thresh=0.0, min_k=min(24, K3), pool=pool):
+    for q, t in pipeline.poses_from_keypoints(kp, bx, rates, kp3d, Kcam, thresh=0.0, min_k=min(24, K3), pool=pool,
+                                              native=not a.numpy_pnp, threads=a.threads):
         writer.append_test(f"img{done:06d}.jpg", q, t)
         done += 1
 t_host = time.perf_counter() - t0
@@ -94,4 +98,4 @@ os.makedirs(a.out, exist_ok=True)
 path = writer.export(out_dir=a.out, suffix="e2e")
 print(f"{a.variant}: {done} images, batch {a.batch}: gpu stage {done / t_gpu:.0f} images/s "
       f"({t_gpu / nb * 1e3:.2f} ms per batch incl. {a.batch * 2.3:.0f} MB H2D), "
-      f"host PnP stage {done / t_host:.0f} images/s on {max(a.workers, 1)} process(es); CSV: {path}")
+      f"host PnP stage {done / t_host:.0f} images/s ({'numpy, %d process(es)' % max(a.workers, 1) if a.numpy_pnp else 'native'}); CSV: {path}")
