@@ -304,8 +304,15 @@ int build_plan(esahrnet_ctx& c) {
         c.fuse_big = false;
         { Op o; o.kind = OP_STEMRAW; o.out = B.tensor(sw, 0, "stem_raw"); stem_raw = o.out;
           o.aux[0] = B.aux("conv1.weight", sw, g.cin, 3, 3); B.push(o); }
-        { Op o; o.kind = OP_STEM; o.out = B.tensor(sw, 0, "stem1"); B.push(o); }
-        x = B.conv(spec_conv2, c.ops.back().out, -1, true, "stem2");
+        // bn1 + ReLU + conv2 + bn2 + ReLU: the fused stem kernel (conv1 is evaluated a second time inside it,
+        // with bn1 folded; the raw copy above exists only for the skip)
+        DevConv d;
+        d.spec = spec_conv2; d.c0 = 0; d.c1 = sw; d.use_bias = true;
+        d.cinp = pad32(sw); d.coutp = pad32(sw);
+        c.dconvs.push_back(d);
+        Op o; o.kind = OP_STEMF; o.dconv = (int)c.dconvs.size() - 1; o.out = B.tensor(sw, 1, "stem2");
+        B.push(o);
+        x = o.out;
     } else if (c.fuse_big) {       // conv1 recomputed per tile inside the conv2 kernel (stem_fused.hip)
         DevConv d;
         d.spec = spec_conv2; d.c0 = 0; d.c1 = sw; d.use_bias = true;

@@ -407,7 +407,7 @@ def test_hrnet3_intermediates_match_oracle(env):
     with torch.no_grad():
         out_ref = env["hrnet_ref"].forward(sd, cfg, x, taps_ref)
         taps = net.taps(x.cuda())
-    assert {"stem_raw", "stem1", "layer1", "stage4.3", "head0", "head3"} <= set(taps)
+    assert {"stem_raw", "stem2", "layer1", "stage4.3", "head0", "head3"} <= set(taps)
     for name, ref in taps_ref.items():
         if name in taps:
             err = (taps[name].cpu() - ref).abs().max().item()
