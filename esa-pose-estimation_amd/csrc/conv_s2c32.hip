@@ -1,40 +1,79 @@
-// conv_s2c32.hip — 3x3 stride-2 convolution (+ folded-BN bias, ReLU) on the matrix cores, split-bf16,
-// weights in registers: the fuse-down chains and the transition layers
-// (models/seg_hrnet.py:176-220 fuse_layers[i][j], j < i; :343-377 transition layers).
+// conv_s2c32.hip — the "stream" 3x3 convolution (+ folded-BN bias, optional residual, ReLU) on the matrix
+// cores, split-bf16, weights in registers:
+//   stride 2: the fuse-down chains and the transition layers
+//             (models/seg_hrnet.py:176-220 fuse_layers[i][j], j < i; :343-377 transition layers);
+//   stride 1: the BasicBlock / Bottleneck 3x3 convs of the 64..128-channel branches (models/seg_hrnet.py:40-72).
 //
-// A stride-2 conv reads four input pixels per output pixel, so the generic tiling (conv_mfma<3,2,4,2>:
-// one output row per wave, 32 couts per workgroup) is LDS- and L2-bound: 54 LDS reads per 54 MFMAs, and
-// the 9x33 input tile is staged once per 32-cout slice.  With a single 32-channel chunk the whole
-// weight set of a 16-cout tile is 18 fragments = 72 VGPRs, so here
+// The generic tiling (conv_mfma.hip: one output row per wave, weights AND input through LDS) is LDS-bound:
+// 54 LDS reads per 54 MFMAs.  With 32-channel chunks the whole weight set of a 16-cout tile is
+// 18 fragments = 72 VGPRs, so here
 //   * a wave owns one cout tile for the workgroup's lifetime (persistent workgroups, cout-tile index
-//     constant per workgroup): its weights are loaded from global ONCE, never touch LDS;
+//     constant per workgroup): its weights come from global straight into registers, never touch LDS;
 //   * every wave sweeps all rows of the pixel tile: each input-row fragment it reads from LDS feeds up to
-//     two taps of two output rows (54 reads per 108 MFMAs at 64 couts per workgroup);
-//   * the input tile is staged once per 64 (or 32) couts; the next item's tile is prefetched into
+//     three taps of three output rows (60 reads per 216 MFMAs at stride 1);
+//   * the input tile is staged once per 64 (or 32) couts; the next step's tile is prefetched into
 //     registers while the current one is consumed (issue-early / write-late, as in conv_mfma.hip).
-// LDS holds only the 8 operand planes of the input tile (40 KB).
+// LDS holds only the 8 operand planes of the input tile (24..40 KB).
+//
+// Everything around the MFMA stream is kept short and branch-free, because a wave that is not issuing
+// MFMAs leaves its SIMD's matrix pipe to ONE other wave (2 workgroups per CU):
+//   * global accesses go through buffer descriptors: an out-of-image pixel / row / column is a single
+//     select of an out-of-range offset (loads return 0 = the zero padding, stores are dropped), no
+//     exec-mask branches, 32-bit offsets, the image base in the scalar offset;
+//   * the item decode divides by multiplication (host-computed reciprocals);
+//   * bias and weights of the next step are loaded a phase or more ahead of their use;
+//   * LDS operand reads run S2_RD rows ahead of the MFMAs that consume them.
 #include "conv_cfg.h"
 #include "kernels.h"
 #include "sb.h"
 
+#ifdef S2_TRACE
+// debug build only (tools/trace_s2.py, -DS2_TRACE=<Cinp>): per-wave cycle stamps of the stream kernel's phases
+__device__ unsigned long long g_s2_trace[64 * 4 * 8 * 16];
+extern "C" int esa_debug_s2_trace(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_s2_trace), sizeof(g_s2_trace));
+}
+#endif
+
+#ifndef S2_RD
+#define S2_RD 2          // LDS read-ahead distance (input rows)
+#endif
+
 namespace esa {
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-// MW = cout tiles (of 16) per workgroup: 4 -> wave = cout tile, 4 output rows each;
-//                                        2 -> wave = (cout tile, row half), 2 output rows each
+constexpr uint32_t OOB = 0x80000000u;      // offset >= every descriptor's num_records (all < 2^31)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// tile stream geometry; m_* = floor((2^32 - 1) / d): q = umulhi(b, m) is b / d or one less
+struct StreamGeo {
+    int tiles_x, tiles_y, ctiles, nitems;
+    uint32_t m_ct, m_tx, m_ty;
+};
+__device__ __forceinline__ int div_magic(int b, int d, uint32_t m) {
+    int q = (int)__umulhi((uint32_t)b, m);
+    if (b - q * d >= d) ++q;
+    return q;
+}
+
+// MW = cout tiles (of 16) per workgroup: 4 -> wave = cout tile, TH output rows each;
+//                                        2 -> wave = (cout tile, row half), TH/2 output rows each
 // The workgroup walks a stream of (item, chunk) steps; X of step s+1 is prefetched into registers while
 // step s is consumed; the weight registers are a ring of three kx-thirds: as soon as phase kx of step s
 // is done, the (kx) third of step s+1 is loaded into the same registers (3 phases of cover, no extra
 // VGPRs).  Single-chunk layers whose cout slice does not change keep their weights for the whole launch.
 template <int S, int TH, int MW>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, int tiles_x, int tiles_y, int ctiles,
-                                                                int nitems) {
+__global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, StreamGeo geo) {
     using S2C = ConvCfg<3, S, TH, 2>;
-    constexpr int S2_TH = TH;
     constexpr int RG = 4 / MW;                  // row groups
-    constexpr int NT = S2_TH / RG;              // output rows per wave
+    constexpr int NT = TH / RG;                 // output rows per wave
     constexpr int ROWS = (NT - 1) * S + 3;      // input rows a wave touches
+    constexpr int RD = (S == 1 && TH == 16) ? 0 : S2_RD;     // the 16-row tile has no registers to spare
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -42,44 +81,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
     const int mw = wave % MW, rg = wave / MW;
     const int G = gridDim.x;
     const int nchunks = p.Cinp >> 5;
-    const int pixb = p.Cinp * 4;
+    const int pixb = p.Cinp * 4, opix = p.Coutp * 4;
+    const int ximg = p.H * p.W * pixb, yimg = p.OH * p.OW * opix;        // bytes per image (< 2^31, host-checked)
     int item = xcd_contiguous(blockIdx.x, G);
-    if (item >= nitems) return;
+    if (item >= geo.nitems) return;
+#ifdef S2_TRACE
+    const unsigned long long t_begin = clock64();
+#endif
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (uint32_t)p.N * (uint32_t)ximg);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, (uint32_t)p.N * (uint32_t)yimg);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res : p.y, p.res ? (uint32_t)p.N * (uint32_t)yimg : 0u);
 
-    // ---- staging map of the item being prefetched (same unit map as conv_mfma.hip) ---------------
-    int xg[S2C::XITER];
+    // ---- staging map: thread -> (operand plane jst, tile pixel q0 + 32*it), fixed for the launch ----
     const int jst = tid & 7, q0 = tid >> 3;
     char* xwr = xs + S2C::plane_off(jst) + q0 * 16;
-    const char* xn;
+    int qyx[S2C::XITER];                        // tile-local (row << 8 | column) of the pixel, -1 beyond the tile
+#pragma unroll
+    for (int it = 0; it < S2C::XITER; ++it) {
+        const int q = q0 + it * 32;
+        const int qy = q / S2C::IW, qx = q - qy * S2C::IW;
+        qyx[it] = q < S2C::NPIX ? (qy << 8 | qx) : -1;
+    }
+    uint32_t xg[S2C::XITER];                    // byte offsets inside the image of the item being prefetched
     int s_n, s_oy0, s_ox0, s_ct;
-#define S2_DECODE(ITEM)                                                                           \
-    {                                                                                             \
-        int b_ = (ITEM);                                                                          \
-        s_ct = b_ % ctiles; b_ /= ctiles;                                                         \
-        const int tx_ = b_ % tiles_x; b_ /= tiles_x;                                              \
-        const int ty_ = b_ % tiles_y;                                                             \
-        s_n = b_ / tiles_y;                                                                       \
-        s_oy0 = ty_ * S2_TH; s_ox0 = tx_ * TW;                                                    \
-        xn = p.x + (size_t)s_n * p.H * p.W * pixb;                                                \
-        _Pragma("unroll") for (int it = 0; it < S2C::XITER; ++it) {                               \
-            const int q = q0 + it * 32;                                                           \
-            const int qy = q / S2C::IW, qx = q - qy * S2C::IW;                                    \
-            const int gy = s_oy0 * S - 1 + qy, gx = s_ox0 * S - 1 + qx;                           \
-            const bool inside = q < S2C::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;      \
-            xg[it] = inside ? ((gy * p.W + gx) * pixb + jst * 16) : -1;                           \
-        }                                                                                         \
-    }
-    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    auto decode = [&](int it_) {
+        const int q1 = div_magic(it_, geo.ctiles, geo.m_ct);
+        s_ct = it_ - q1 * geo.ctiles;
+        const int q2 = div_magic(q1, geo.tiles_x, geo.m_tx);
+        const int tx = q1 - q2 * geo.tiles_x;
+        s_n = div_magic(q2, geo.tiles_y, geo.m_ty);
+        const int ty = q2 - s_n * geo.tiles_y;
+        s_oy0 = ty * TH;
+        s_ox0 = tx * TW;
+        const int gy0 = s_oy0 * S - 1, gx0 = s_ox0 * S - 1;
+#pragma unroll
+        for (int it = 0; it < S2C::XITER; ++it) {
+            const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
+            const bool inside = qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            xg[it] = inside ? (uint32_t)((gy * p.W + gx) * pixb + jst * 16) : OOB;
+        }
+    };
     u32x4 xr[S2C::XITER];
-#define S2_PREFETCH(CH)                                                                           \
-    {                                                                                             \
-        _Pragma("unroll") for (int it = 0; it < S2C::XITER; ++it) {                               \
-            u32x4 v = {0, 0, 0, 0};                                                               \
-            if (xg[it] >= 0) v = *reinterpret_cast<const u32x4*>(xn + xg[it] + (CH) * 128);       \
-            xr[it] = v;                                                                           \
-        }                                                                                         \
-    }
+    auto prefetch = [&](int n_, int ch) {
+        const int so = n_ * ximg + ch * 128;
+#pragma unroll
+        for (int it = 0; it < S2C::XITER; ++it) xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xg[it], so, 0);
+    };
     // weights of (cout slice CT, chunk CH), third KX -> registers wh/wl[ky*3 + KX]
+    bf16x8 wh[9], wl[9];
 #define S2_LOAD_W(CT, CH, KX)                                                                     \
     {                                                                                             \
         const uint4* ws_ = p.w + ((size_t)((CT) * MW + mw) * nchunks + (CH)) * (9 * 128) + lane;  \
@@ -90,57 +139,77 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
     }
 
     const char* xrd = xs + S2C::plane_off(2 * g) + ((rg * NT * S) * S2C::IW + (lane & 15) * S) * 16;
-    const int opix = p.Coutp * 4;
-    bf16x8 wh[9], wl[9];
 
-    S2_DECODE(item)
-    S2_PREFETCH(0)
+    decode(item);
+    prefetch(s_n, 0);
     S2_LOAD_W(s_ct, 0, 0)
     S2_LOAD_W(s_ct, 0, 1)
     S2_LOAD_W(s_ct, 0, 2)
     int n = s_n, oy0 = s_oy0, ox0 = s_ox0, ct = s_ct;      // the item being computed
+    f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + (ct * MW + mw) * 16 + g * 4);
     int c = 0;
     bool first = true;
     f32x4 acc[NT];
+#ifdef S2_TRACE
+    int tstep = 0;
+    const bool ton = S == 1 && p.Cinp == S2_TRACE && blockIdx.x < 64 && lane == 0;
+    unsigned long long* const trow = g_s2_trace + (blockIdx.x * 4 + wave) * 8 * 16;
+#define TR(EV) if (ton && tstep < 8) trow[tstep * 16 + (EV)] = clock64();
+    if (ton) {
+        trow[15] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+        trow[9] = wall_clock64();
+        trow[10] = t_begin;
+    }
+#else
+#define TR(EV)
+#endif
     while (true) {
+        TR(0)
         const bool last_chunk = c + 1 == nchunks;
-        const bool more = !last_chunk || item + G < nitems;          // is there a step s+1?
+        const bool more = !last_chunk || item + G < geo.nitems;          // is there a step s+1?
         if (!first) __syncthreads();            // previous step's MFMAs are done reading the planes
         first = false;
+        TR(1)
 #pragma unroll
         for (int it = 0; it < S2C::XITER; ++it)
             if (q0 + it * 32 < S2C::NPIX) *reinterpret_cast<u32x4*>(xwr + it * 512) = xr[it];
+        TR(2)
         __syncthreads();
-        // step s+1: next chunk of this item, or chunk 0 of the workgroup's next item
+        TR(3)
+        // step s+1: next chunk of this item, or chunk 0 of the workgroup's next item (the last step of the
+        // stream prefetches its own tile again: harmless, keeps the loop free of branches around loads)
         int nct = ct, nch = c + 1;
         if (last_chunk) {
             nch = 0;
             if (more) {
-                S2_DECODE(item + G)
+                decode(item + G);
                 nct = s_ct;
             }
         }
-        if (more) S2_PREFETCH(nch)
+        prefetch(s_n, nch);
+        TR(4)
         const bool reload = more && (nchunks > 1 || nct != ct);
         const int co = (ct * MW + mw) * 16 + g * 4;
         if (c == 0) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = bv;
         }
+        // output rows of this wave: 32-bit offsets inside the image, OOB for pixels outside it
+        const int rox = ox0 + (lane & 15), roy = oy0 + rg * NT;
+        const uint32_t o0 = rox < p.OW ? (uint32_t)((roy * p.OW + rox) * opix + chunk_ofs(co, g)) : OOB;
+        const int orow = p.OW * opix, yso = n * yimg;
+        const int nrows = p.OH - roy;                                   // rows t < nrows exist
         // residual (last chunk only): two halves of the wave's rows, each loaded a phase or two before it
         // is folded into the accumulators, as 16-byte chunks (sb.h)
         constexpr int NH = NT >= 2 ? NT / 2 : 1;
-        uint4 rc[NH];
+        u32x4 rc[NH];
         const bool do_res = last_chunk && p.res != nullptr;
-        const int rox = ox0 + (lane & 15);
 #define S2_RES_LOAD(HALF)                                                                         \
         if (do_res) {                                                                             \
             _Pragma("unroll") for (int t = 0; t < NH; ++t) {                                      \
-                const int oy_ = oy0 + rg * NT + (HALF) * NH + t;                                  \
-                rc[t] = make_uint4(0, 0, 0, 0);                                                   \
-                if ((HALF) * NH + t < NT && oy_ < p.OH && rox < p.OW)                             \
-                    rc[t] = *reinterpret_cast<const uint4*>(p.res + ((size_t)(n * p.OH + oy_) * p.OW + rox) * opix + chunk_ofs(co, g)); \
+                const int tt = (HALF) * NH + t;                                                   \
+                const uint32_t ro_ = (tt < NT && tt < nrows) ? o0 + (uint32_t)(tt * orow) : OOB;  \
+                rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ro_, yso, 0);              \
             }                                                                                     \
         }
 #define S2_RES_ADD(HALF)                                                                          \
@@ -148,20 +217,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
             _Pragma("unroll") for (int t = 0; t < NH; ++t)                                        \
                 if ((HALF) * NH + t < NT) {                                                       \
                     uint2 rh_, rl_;                                                               \
-                    chunk_to_quad(rc[t], rh_, rl_);                                               \
+                    chunk_to_quad(make_uint4(rc[t][0], rc[t][1], rc[t][2], rc[t][3]), rh_, rl_);  \
                     float r_[4];                                                                  \
                     join4(rh_, rl_, r_);                                                          \
                     _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[(HALF) * NH + t][i] += r_[i]; \
                 }                                                                                 \
         }
         S2_RES_LOAD(0)
+        bf16x8 fh[RD + 1], fo[RD + 1];
+#define S2_READ(IDX)                                                                              \
+        {                                                                                         \
+            const int off_ = (((IDX) % ROWS) * S2C::IW + (IDX) / ROWS) * 16;                      \
+            fh[(IDX) % (RD + 1)] = *reinterpret_cast<const bf16x8*>(xrd + off_);                  \
+            fo[(IDX) % (RD + 1)] = *reinterpret_cast<const bf16x8*>(xrd + off_ + S2C::LO_OFF);    \
+        }
+#pragma unroll
+        for (int r = 0; r < RD; ++r) S2_READ(r)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) {
-                const int off = (i * S2C::IW + kx) * 16;
-                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xrd + off);
-                const bf16x8 xo = *reinterpret_cast<const bf16x8*>(xrd + off + S2C::LO_OFF);
+                const int idx = kx * ROWS + i;
+                if (idx + RD < 3 * ROWS) {
+                    S2_READ(idx + RD)
+                    __builtin_amdgcn_sched_barrier(0);       // keep the read ahead of this row's MFMAs
+                }
+                const bf16x8 xh = fh[idx % (RD + 1)];
+                const bf16x8 xo = fo[idx % (RD + 1)];
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int d = i - ky;
@@ -179,44 +261,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, i
                 if (NT >= 2) S2_RES_LOAD(1)
             }
             if (kx == 2 && NT >= 2) S2_RES_ADD(1)
+            TR(5 + kx)
         }
+#undef S2_READ
 #undef S2_RES_LOAD
 #undef S2_RES_ADD
         if (last_chunk) {
             // ---- epilogue: ReLU, split, 16-byte chunk stores ---------------------------------------
-            const int ox = ox0 + (lane & 15);
+            const int rfl = relu_floor(p.relu);                  // branch-free (see sb.h)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int oy = oy0 + rg * NT + t;
                 float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-                {
-                    const int rfl = relu_floor(p.relu);          // branch-free (see sb.h)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = relu_opt(v[i], rfl);
-                }
+                for (int i = 0; i < 4; ++i) v[i] = relu_opt(v[i], rfl);
                 uint2 hi, lo;
                 split4(v, hi, lo);
                 const uint4 ch = quad_to_chunk(hi, lo);
-                if (oy < p.OH && ox < p.OW)
-                    *reinterpret_cast<uint4*>(p.y + ((size_t)(n * p.OH + oy) * p.OW + ox) * opix + chunk_ofs(co, g)) = ch;
+                const u32x4 cv = {ch.x, ch.y, ch.z, ch.w};
+                const uint32_t so_ = t < nrows ? o0 + (uint32_t)(t * orow) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(cv, ry, (int)so_, yso, 0);
             }
+            TR(8)
+#ifdef S2_TRACE
+            if (ton && !more) {
+                trow[11] = clock64();
+                trow[12] = wall_clock64();
+            }
+#endif
             if (!more) break;
+            if (nct != ct) bv = *reinterpret_cast<const f32x4*>(p.bias + (nct * MW + mw) * 16 + g * 4);
             item += G;
             n = s_n; oy0 = s_oy0; ox0 = s_ox0; ct = s_ct;
             c = 0;
         } else {
             ++c;
         }
+#ifdef S2_TRACE
+        ++tstep;
+#endif
     }
-#undef S2_DECODE
-#undef S2_PREFETCH
+#undef TR
 #undef S2_LOAD_W
 }
+
+uint32_t magic_of(int d) { return (uint32_t)(0xffffffffull / (uint64_t)d); }
 
 template <int S, int TH, int MW>
 int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
     using S2C = ConvCfg<3, S, TH, 2>;
-    constexpr int S2_TH = TH;
     auto kern = conv_s2c32_kernel<S, TH, MW>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -225,10 +317,16 @@ int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + S2_TH - 1) / S2_TH;
-    const int ctiles = p.Coutp / (16 * MW);
-    const long long nitems = (long long)p.N * tiles_y * tiles_x * ctiles;
+    StreamGeo geo;
+    geo.tiles_x = (p.OW + TW - 1) / TW;
+    geo.tiles_y = (p.OH + TH - 1) / TH;
+    geo.ctiles = p.Coutp / (16 * MW);
+    const long long nitems = (long long)p.N * geo.tiles_y * geo.tiles_x * geo.ctiles;
     if (nitems <= 0 || nitems > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    geo.nitems = (int)nitems;
+    geo.m_ct = magic_of(geo.ctiles);
+    geo.m_tx = magic_of(geo.tiles_x);
+    geo.m_ty = magic_of(geo.tiles_y);
     static int slots = 0;
     if (!slots) {
         int dev = 0, cus = 256;
@@ -239,17 +337,18 @@ int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
         slots = 2 * cus;
     }
     int grid = (int)(nitems < slots ? nitems : slots);
-    if (grid > ctiles) grid -= grid % ctiles;   // grid stride keeps the cout slice of a workgroup constant
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), S2C::XBYTES, stream, p, tiles_x, tiles_y, ctiles,
-                       (int)nitems);
+    if (grid > geo.ctiles) grid -= grid % geo.ctiles;   // grid stride keeps the cout slice of a workgroup constant
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), S2C::XBYTES, stream, p, geo);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
+// whole tensors must be addressable with 31-bit byte offsets (buffer descriptors, OOB marker 2^31)
 bool conv_s2c32_supported(const ConvParams& p) {
     return (p.Cinp & 31) == 0 && p.Cinp >= 32 && (p.Coutp & 31) == 0 && !p.out_f32 &&
-           (long long)p.H * p.W * p.Cinp * 4 <= 0x7fffffffLL;
+           (long long)p.N * p.H * p.W * p.Cinp * 4 < 0x7fffffffLL &&
+           (long long)p.N * p.OH * p.OW * p.Coutp * 4 < 0x7fffffffLL;
 }
 
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream) {
@@ -257,9 +356,11 @@ int launch_conv_s2c32(const ConvParams& p, hipStream_t stream) {
     return (p.Coutp % 64 == 0) ? launch_s2c32_t<2, 4, 4>(p, stream) : launch_s2c32_t<2, 4, 2>(p, stream);
 }
 
-// the same scheme for stride 1 (TH = 16, a wave = one cout tile x 8 rows, 32 couts per workgroup)
+// the same scheme for stride 1: 64 couts x 8 rows per workgroup (wave = cout tile) where the layer has a
+// multiple of 64 couts, else 32 couts x 16 rows (wave = cout tile x 8 rows)
 int launch_conv_s1w(const ConvParams& p, hipStream_t stream) {
     if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
+    if (p.Coutp % 64 == 0) return launch_s2c32_t<1, 8, 4>(p, stream);
     return launch_s2c32_t<1, 16, 2>(p, stream);
 }
 
