@@ -30,8 +30,12 @@
 #ifdef S2_TRACE
 // debug build only (tools/trace_s2.py, -DS2_TRACE=<Cinp>): per-wave cycle stamps of the stream kernel's phases
 __device__ unsigned long long g_s2_trace[64 * 4 * 8 * 16];
+__device__ unsigned long long g_s2_wg[1024 * 2];       // wall clock (100 MHz) at start / end of every workgroup
 extern "C" int esa_debug_s2_trace(void* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_s2_trace), sizeof(g_s2_trace));
+}
+extern "C" int esa_debug_s2_wg(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_s2_wg), sizeof(g_s2_wg));
 }
 #endif
 
@@ -87,6 +91,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
     if (item >= geo.nitems) return;
 #ifdef S2_TRACE
     const unsigned long long t_begin = clock64();
+    const bool wgon = S == 1 && p.Cinp == S2_TRACE && blockIdx.x < 1024 && tid == 0;
+    if (wgon) g_s2_wg[blockIdx.x * 2] = wall_clock64();
 #endif
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (uint32_t)p.N * (uint32_t)ximg);
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, (uint32_t)p.N * (uint32_t)yimg);
@@ -152,8 +158,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
     f32x4 acc[NT];
 #ifdef S2_TRACE
     int tstep = 0;
-    const bool ton = S == 1 && p.Cinp == S2_TRACE && blockIdx.x < 64 && lane == 0;
-    unsigned long long* const trow = g_s2_trace + (blockIdx.x * 4 + wave) * 8 * 16;
+    // traced: the first 32 workgroups and the first 32 of the second half (the second workgroup of a CU)
+    const int tslot = (int)blockIdx.x < 32 ? (int)blockIdx.x : (int)blockIdx.x - (G >> 1) + 32;
+    const bool ton = S == 1 && p.Cinp == S2_TRACE && tslot >= 0 && tslot < 64 && ((int)blockIdx.x < 32 || (int)blockIdx.x >= (G >> 1)) && lane == 0;
+    unsigned long long* const trow = g_s2_trace + ((ton ? tslot : 0) * 4 + wave) * 8 * 16;
 #define TR(EV) if (ton && tstep < 8) trow[tstep * 16 + (EV)] = clock64();
     if (ton) {
         trow[15] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
@@ -287,6 +295,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
                 trow[11] = clock64();
                 trow[12] = wall_clock64();
             }
+#endif
+#ifdef S2_TRACE
+            if (wgon && !more) g_s2_wg[blockIdx.x * 2 + 1] = wall_clock64();
 #endif
             if (!more) break;
             if (nct != ct) bv = *reinterpret_cast<const f32x4*>(p.bias + (nct * MW + mw) * 16 + g * 4);

@@ -23,7 +23,7 @@ assert rc == 0, rc
 t = buf.reshape(64, 4, 8, 16).astype(np.int64)
 base = t[:, :, 0, 0].min()
 names = ["start", "bar1", "ldsw", "bar2", "pref", "kx0", "kx1", "kx2", "epi"]
-for wg in (0,):
+for wg in (0, 32):
     for w in range(4):
         hw = int(t[wg, w, 0, 15])
         print(f"wg {wg} wave {w} hw_id {hw:#x}")
@@ -39,6 +39,23 @@ print("wave lifetime: ticks median", np.median([l[0] for l in life]), " wall(100
       " prologue ticks median", np.median([l[2] for l in life]))
 w0 = t[:, :, 0, 9][t[:, :, 0, 11] > 0]; w1 = t[:, :, 0, 12][t[:, :, 0, 11] > 0]
 print("first start -> last end over traced WGs (100 MHz ticks):", int(w1.max() - w0.min()), " start spread", int(w0.max() - w0.min()))
+wg = np.zeros(2048, dtype=np.uint64)
+lib.esa_debug_s2_wg.argtypes = [ctypes.c_void_p]
+assert lib.esa_debug_s2_wg(wg.ctypes.data) == 0
+wg = wg.reshape(1024, 2).astype(np.int64)
+wg = wg[wg[:, 0] > 0]
+t0 = wg[:, 0].min()
+st = np.sort(wg[:, 0] - t0); en = np.sort(wg[:, 1] - t0)
+print(f"{len(wg)} workgroups: start (10 ns ticks) p0 {st[0]} p25 {st[len(st)//4]} p50 {st[len(st)//2]} p75 {st[3*len(st)//4]} p100 {st[-1]};"
+      f" end p0 {en[0]} p50 {en[len(en)//2]} p100 {en[-1]}; lifetime median {np.median(wg[:,1]-wg[:,0])}")
+for x in range(8):
+    e = wg[x::8, 1] - t0
+    print(f"  XCD {x}: end min {e.min()} median {int(np.median(e))} max {e.max()}")
+e = wg[:, 1] - t0
+half = len(wg) // 2
+print("  first-half WGs end median", int(np.median(e[:half])), " second-half", int(np.median(e[half:])))
+order = np.argsort(wg[:, 0] - t0)
+print("start by blockIdx (every 32nd):", [(int(i), int(wg[i, 0] - t0)) for i in range(0, len(wg), 32)])
 # aggregate: mean phase durations over all traced waves/steps
 d = {}
 for wg in range(64):
@@ -54,5 +71,15 @@ for wg in range(64):
                 d.setdefault("kx2->epi", []).append(int(r[8] - r[7]))
             if s + 1 < 8 and t[wg, w, s + 1, 0]:
                 d.setdefault("step total", []).append(int(t[wg, w, s + 1, 0] - r[0]))
+for half, rng in (("first WG of a CU", range(0, 32)), ("second WG of a CU", range(32, 64))):
+    tot = []
+    for wg_ in rng:
+        for w in range(4):
+            r = t[wg_, w]
+            st_ = [int(r[s_ + 1, 0] - r[s_, 0]) for s_ in range(3) if r[s_ + 1, 0] and r[s_, 0] and r[s_ + 1, 0] > r[s_, 0]]
+            if len(st_) == 3:
+                tot.append(st_ + [int(r[3, 8] - r[3, 0])])
+    if tot:
+        print(half, "step durations (cycles, median over waves) steps 0..3:", np.median(np.array(tot), axis=0))
 for k, v in d.items():
     print(f"{k:14s} mean {np.mean(v):8.0f}  median {np.median(v):8.0f}  min {np.min(v):7d} max {np.max(v):7d}  n {len(v)}")
