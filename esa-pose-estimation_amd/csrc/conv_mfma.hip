@@ -536,14 +536,14 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
 #define ESA_S1W 1
 #endif
     if (k == 3 && stride == 1) {
-        // layers with many 16x16x32-cout items per image (>= two per workgroup slot at batch 32): the register-weight stream kernel
-        // (conv_s2c32.hip; measured 5-15 % faster there: cross-item prefetch, two barriers per chunk, no
-        // weight traffic through LDS); smaller grids stay on the LDS weight ring below
-        // (the choice must not depend on the batch size: a crop's result is bit-identical in any batch)
+        // the register-weight stream kernel (conv_s2c32.hip: cross-item prefetch, two barriers per chunk, no weight
+        // traffic through LDS) wherever an image has at least 8 of its 16x16x32-cout items: measured 5-15 % faster
+        // than the LDS weight ring below on the 64/128/256-channel branches.  The choice must not depend on
+        // the batch size: a crop's result is bit-identical in any batch.
         const long long items_per_image = (long long)((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);
-        // (deep contractions amortise the ring's prologue and share each weight chunk between four waves through
-        // LDS: the 480 -> 480 3x3 of seg_hrnet3 runs 432 TFLOP/s on the ring, 396 on the stream kernel)
-        if (ESA_S1W && items_per_image >= 32 && p.Cinp <= 128 && conv_s2c32_supported(p)) return launch_conv_s1w(p, stream);
+        // (very deep contractions amortise the ring's prologue and share each weight chunk between four waves
+        // through LDS: the 480 -> 480 3x3 of seg_hrnet3 runs 436 TFLOP/s on the ring, 400 on the stream kernel)
+        if (ESA_S1W && items_per_image >= 8 && p.Cinp <= 256 && conv_s2c32_supported(p)) return launch_conv_s1w(p, stream);
         // deep, small-resolution layers (e.g. 256 ch @ 16x16, batch 32) have too few 16x16 tiles to
         // fill 2 workgroups on every CU: halve the tile height there
         const long long items16 = (long long)p.N * ((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);
