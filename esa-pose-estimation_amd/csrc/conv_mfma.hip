@@ -528,43 +528,71 @@ int launch_t(const ConvParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
-    if ((p.Cinp & 31) || (p.Coutp & 31)) return (int)hipErrorInvalidValue;
-    // one image is addressed with 32-bit byte offsets inside the kernel
-    if ((long long)p.H * p.W * p.Cinp * 4 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
 #ifndef ESA_S1W
 #define ESA_S1W 1
 #endif
-    if (k == 3 && stride == 1) {
-        // the register-weight stream kernel (conv_s2c32.hip: cross-item prefetch, two barriers per chunk, no weight
-        // traffic through LDS) wherever an image has at least 8 of its 16x16x32-cout items: measured 5-15 % faster
-        // than the LDS weight ring below on the 64/128/256-channel branches.  The choice must not depend on
-        // the batch size: a crop's result is bit-identical in any batch.
-        const long long items_per_image = (long long)((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);
-        // (very deep contractions amortise the ring's prologue and share each weight chunk between four waves
-        // through LDS: the 480 -> 480 3x3 of seg_hrnet3 runs 436 TFLOP/s on the ring, 400 on the stream kernel)
-        if (ESA_S1W && items_per_image >= 8 && p.Cinp <= 256 && conv_s2c32_supported(p)) return launch_conv_s1w(p, stream);
-        // deep, small-resolution layers (e.g. 256 ch @ 16x16, batch 32) have too few 16x16 tiles to
-        // fill 2 workgroups on every CU: halve the tile height there
-        const long long items16 = (long long)p.N * ((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);
-        if (p.Cinp > 32 && items16 < 2LL * 256 * 3 / 4 && p.OH > 8) return launch_t<3, 1, 8, 2>(p, stream);
-        return launch_t<3, 1, 16, 2>(p, stream);
-    }
 #ifndef ESA_S2C32
 #define ESA_S2C32 1
 #endif
-    if (k == 3 && stride == 2) {
-        if (ESA_S2C32 && conv_s2c32_supported(p)) return launch_conv_s2c32(p, stream);     // conv_s2c32.hip
-        return launch_t<3, 2, 4, 2>(p, stream);
-    }
 #ifndef ESA_C1X1
 #define ESA_C1X1 1
 #endif
-    if (k == 1 && stride == 1) {
-        if (ESA_C1X1 && conv1x1_supported(p)) return launch_conv1x1(p, stream);          // conv1x1.hip
-        return launch_t<1, 1, 16, 2>(p, stream);
+
+namespace {
+// which kernel serves a convolution.  The choice must not depend on the batch size: a crop's result is
+// bit-identical in any batch (tests/test_gpu_parity.py).
+enum Choice { C_NONE, C_STREAM_S1, C_TILE_S1_8, C_TILE_S1_16, C_STREAM_S2, C_TILE_S2, C_1X1, C_TILE_1X1 };
+Choice choose_conv(const ConvParams& p, int k, int stride) {
+    if ((p.Cinp & 31) || (p.Coutp & 31)) return C_NONE;
+    // one image is addressed with 32-bit byte offsets inside the kernels
+    if ((long long)p.H * p.W * p.Cinp * 4 > 0x7fffffffLL) return C_NONE;
+    if (k == 3 && stride == 1) {
+        // the register-weight stream kernel (conv_s2c32.hip: cross-item prefetch, two barriers per chunk, no weight
+        // traffic through LDS) wherever an image has at least 8 of its 16x16x32-cout items: measured 5-15 % faster
+        // than the LDS weight ring on the 64/128/256-channel branches
+        const long long items_per_image = (long long)((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);
+        // (very deep contractions amortise the ring's prologue and share each weight chunk between four waves
+        // through LDS: the 480 -> 480 3x3 of seg_hrnet3 runs 436 TFLOP/s on the ring, 400 on the stream kernel)
+        if (ESA_S1W && items_per_image >= 8 && p.Cinp <= 256 && conv_s2c32_supported(p)) return C_STREAM_S1;
+        // deep, small-resolution layers have too few 16x16 tiles to fill 2 workgroups on every CU: halve the
+        // tile height there
+        if (p.Cinp > 32 && items_per_image < 12 && p.OH > 8) return C_TILE_S1_8;
+        return C_TILE_S1_16;
     }
-    return (int)hipErrorInvalidValue;
+    if (k == 3 && stride == 2) return ESA_S2C32 && conv_s2c32_supported(p) ? C_STREAM_S2 : C_TILE_S2;
+    if (k == 1 && stride == 1) return ESA_C1X1 && conv1x1_supported(p) ? C_1X1 : C_TILE_1X1;
+    return C_NONE;
+}
+}  // namespace
+
+int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
+    switch (choose_conv(p, k, stride)) {
+        case C_STREAM_S1: return launch_conv_s1w(p, stream);
+        case C_TILE_S1_8: return launch_t<3, 1, 8, 2>(p, stream);
+        case C_TILE_S1_16: return launch_t<3, 1, 16, 2>(p, stream);
+        case C_STREAM_S2: return launch_conv_s2c32(p, stream);
+        case C_TILE_S2: return launch_t<3, 2, 4, 2>(p, stream);
+        case C_1X1: return launch_conv1x1(p, stream);
+        case C_TILE_1X1: return launch_t<1, 1, 16, 2>(p, stream);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+// name of the __global__ function launch_conv() runs for these parameters, as rocprofv3 prints it (without
+// namespaces and argument list) — the per-launch tables of bench.py / tools/profile_ops.py group by it
+const char* conv_kernel_name(const ConvParams& p, int k, int stride) {
+    const bool ring = ESA_CONV_RING && p.Cinp > 32;
+    const bool persist = p.Cinp == 32;
+    switch (choose_conv(p, k, stride)) {
+        case C_STREAM_S1: return p.Coutp % 64 == 0 ? "conv_s2c32_kernel<1, 8, 4>" : "conv_s2c32_kernel<1, 16, 2>";
+        case C_TILE_S1_8: return ring ? "conv_mfma_ring_kernel<1, 8, 2>" : persist ? "conv_mfma_kernel<3, 1, 8, 2, true>" : "conv_mfma_kernel<3, 1, 8, 2, false>";
+        case C_TILE_S1_16: return ring ? "conv_mfma_ring_kernel<1, 16, 2>" : persist ? "conv_mfma_kernel<3, 1, 16, 2, true>" : "conv_mfma_kernel<3, 1, 16, 2, false>";
+        case C_STREAM_S2: return p.Coutp % 64 == 0 ? "conv_s2c32_kernel<2, 4, 4>" : "conv_s2c32_kernel<2, 4, 2>";
+        case C_TILE_S2: return ring ? "conv_mfma_ring_kernel<2, 4, 2>" : persist ? "conv_mfma_kernel<3, 2, 4, 2, true>" : "conv_mfma_kernel<3, 2, 4, 2, false>";
+        case C_1X1: return "conv1x1_kernel";
+        case C_TILE_1X1: return "conv_mfma_kernel<1, 1, 16, 2, false>";
+        default: return "none";
+    }
 }
 
 size_t packed_weight_bytes(int coutp, int cinp, int k) {

@@ -19,6 +19,8 @@ struct ConvParams {
 };
 // k in {1,3}, stride in {1,2}, pad = (k-1)/2.  Returns hipError_t as int.
 int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream);
+// name of the kernel launch_conv() runs for these parameters (only shapes / flags / res != nullptr are looked at)
+const char* conv_kernel_name(const ConvParams& p, int k, int stride);
 // 3x3 stride-2, Cinp == 32, no residual: weights in registers, one cout tile per wave (conv_s2c32.hip)
 bool conv_s2c32_supported(const ConvParams& p);
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream);

@@ -1215,7 +1215,14 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             const DevConv& d = h->dconvs[o.dconv];
             const ConvSpec& s = h->specs[d.spec];
             const Tensor& to = h->tensors[o.out];
-            snprintf(out->kernel, sizeof out->kernel, "conv_mfma<%d,%d>", s.k, s.stride);
+            {
+                const Tensor& ti = h->tensors[o.in];
+                esa::ConvParams q{};
+                q.N = n; q.H = lh[ti.level]; q.W = lw[ti.level]; q.OH = lh[to.level]; q.OW = lw[to.level];
+                q.Cinp = d.cinp; q.Coutp = d.coutp; q.out_f32 = d.out_f32;
+                q.res = o.res >= 0 ? reinterpret_cast<const char*>(h) : nullptr;     // only tested against nullptr
+                snprintf(out->kernel, sizeof out->kernel, "%s", esa::conv_kernel_name(q, s.k, s.stride));
+            }
             if (d.c0 != 0 || d.c1 != s.cin) snprintf(out->label, sizeof out->label, "%s[:, %d:%d]", s.name.c_str(), d.c0, d.c1);
             else snprintf(out->label, sizeof out->label, "%s", s.name.c_str());
             out->flops = 2.0 * n * lh[to.level] * lw[to.level] * s.cout * (d.c1 - d.c0) * s.k * s.k;

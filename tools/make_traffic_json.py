@@ -18,24 +18,23 @@ for f in sorted(glob.glob(os.path.join(root, "pass*", "*", "*_counter_collection
         n = r["Kernel_Name"].replace("(anonymous namespace)::", "")
         if "esa::" not in n:
             continue
-        if "conv_s2c32_kernel<1" in n:                # stream kernel template args are <stride, TH, MW>, always 3x3
-            key = "conv_mfma<3,1>"
-        elif "conv_s2c32_kernel<2" in n:
-            key = "conv_mfma<3,2>"
-        elif "conv1x1_kernel" in n:
-            key = "conv_mfma<1,1>"
-        elif "conv_mfma_ring_kernel<1" in n:          # ring kernel template args are <stride, TH, MT>, always 3x3
-            key = "conv_mfma<3,1>"
-        elif "conv_mfma_ring_kernel<2" in n:
-            key = "conv_mfma<3,2>"
-        elif "conv_mfma_kernel<3, 1" in n:
-            key = "conv_mfma<3,1>"
-        elif "conv_mfma_kernel<3, 2" in n:
-            key = "conv_mfma<3,2>"
-        elif "conv_mfma_kernel<1, 1" in n:
-            key = "conv_mfma<1,1>"
+        # key = the function name as the per-launch tables print it (esa::conv_kernel_name): no "void", no
+        # namespaces, no argument list; the conv kernels keep their template arguments, the others do not
+        fn = n.replace("void ", "").replace("esa::", "").strip()
+        depth, cut = 0, len(fn)
+        for i, ch in enumerate(fn):
+            if ch == "<":
+                depth += 1
+            elif ch == ">":
+                depth -= 1
+            elif ch == "(" and depth == 0:
+                cut = i
+                break
+        fn = fn[:cut]
+        if fn.startswith(("conv_s2c32_kernel", "conv_mfma_ring_kernel", "conv_mfma_kernel")):
+            key = fn
         else:
-            key = n.split("(")[0].split("::")[-1].split("<")[0].replace("_kernel", "").replace("void ", "").strip()
+            key = fn.split("<")[0].replace("_kernel", "")
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, v in acc.items():

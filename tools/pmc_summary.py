@@ -18,7 +18,7 @@ for f in sorted(glob.glob(os.path.join(root, "pass*", "*", "*_counter_collection
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if "pass1" in f and r["Counter_Name"] == "SQ_WAVES":
             dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-keys = [k for k in agg if any(s in k[0] for s in ("conv_mfma", "fuse", "stem", "final", "keypoints", "head", "bblock"))]
+keys = [k for k in agg if any(s in k[0] for s in ("conv_", "conv1x1", "fuse", "stem", "final", "keypoints", "head", "bblock", "cbam", "crops"))]
 keys.sort(key=lambda k: -sum(dur.get(k, [0])))
 for k in keys:
     d = dur.get(k, [0])
