@@ -39,6 +39,11 @@ extern "C" int esa_debug_s2_wg(void* dst) {
 }
 #endif
 
+// timing experiments (tools/ablate_any.sh): bit mask of parts compiled OUT — 1 X global loads, 2 X LDS writes,
+// 4 weight reloads, 8 MFMAs, 16 barriers, 32 epilogue + residual, 64 LDS operand reads.  0 in the product build.
+#ifndef S2_ABL
+#define S2_ABL 0
+#endif
 #ifndef S2_RD
 #define S2_RD 2          // LDS read-ahead distance (input rows)
 #endif
@@ -131,7 +136,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
     auto prefetch = [&](int n_, int ch) {
         const int so = n_ * ximg + ch * 128;
 #pragma unroll
-        for (int it = 0; it < S2C::XITER; ++it) xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xg[it], so, 0);
+        for (int it = 0; it < S2C::XITER; ++it)
+            if (!(S2_ABL & 1)) xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xg[it], so, 0);
     };
     // weights of (cout slice CT, chunk CH), third KX -> registers wh/wl[ky*3 + KX]
     bf16x8 wh[9], wl[9];
@@ -175,14 +181,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
         TR(0)
         const bool last_chunk = c + 1 == nchunks;
         const bool more = !last_chunk || item + G < geo.nitems;          // is there a step s+1?
-        if (!first) __syncthreads();            // previous step's MFMAs are done reading the planes
+        if (!first && !(S2_ABL & 16)) __syncthreads();            // previous step's MFMAs are done reading the planes
         first = false;
         TR(1)
 #pragma unroll
         for (int it = 0; it < S2C::XITER; ++it)
-            if (q0 + it * 32 < S2C::NPIX) *reinterpret_cast<u32x4*>(xwr + it * 512) = xr[it];
+            if (!(S2_ABL & 2) && q0 + it * 32 < S2C::NPIX) *reinterpret_cast<u32x4*>(xwr + it * 512) = xr[it];
         TR(2)
-        __syncthreads();
+        if (!(S2_ABL & 16)) __syncthreads();
         TR(3)
         // step s+1: next chunk of this item, or chunk 0 of the workgroup's next item (the last step of the
         // stream prefetches its own tile again: harmless, keeps the loop free of branches around loads)
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
         }
         prefetch(s_n, nch);
         TR(4)
-        const bool reload = more && (nchunks > 1 || nct != ct);
+        const bool reload = !(S2_ABL & 4) && more && (nchunks > 1 || nct != ct);
         const int co = (ct * MW + mw) * 16 + g * 4;
         if (c == 0) {
 #pragma unroll
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
         // is folded into the accumulators, as 16-byte chunks (sb.h)
         constexpr int NH = NT >= 2 ? NT / 2 : 1;
         u32x4 rc[NH];
-        const bool do_res = last_chunk && p.res != nullptr;
+        const bool do_res = !(S2_ABL & 32) && last_chunk && p.res != nullptr;
 #define S2_RES_LOAD(HALF)                                                                         \
         if (do_res) {                                                                             \
             _Pragma("unroll") for (int t = 0; t < NH; ++t) {                                      \
@@ -236,8 +242,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
 #define S2_READ(IDX)                                                                              \
         {                                                                                         \
             const int off_ = (((IDX) % ROWS) * S2C::IW + (IDX) / ROWS) * 16;                      \
-            fh[(IDX) % (RD + 1)] = *reinterpret_cast<const bf16x8*>(xrd + off_);                  \
-            fo[(IDX) % (RD + 1)] = *reinterpret_cast<const bf16x8*>(xrd + off_ + S2C::LO_OFF);    \
+            if (!(S2_ABL & 64)) {                                                                 \
+                fh[(IDX) % (RD + 1)] = *reinterpret_cast<const bf16x8*>(xrd + off_);              \
+                fo[(IDX) % (RD + 1)] = *reinterpret_cast<const bf16x8*>(xrd + off_ + S2C::LO_OFF); \
+            } else if ((IDX) < RD + 1) {                                                          \
+                fh[(IDX) % (RD + 1)] = wh[(IDX) % 9];                                             \
+                fo[(IDX) % (RD + 1)] = wl[(IDX) % 9];                                             \
+            }                                                                                     \
         }
 #pragma unroll
         for (int r = 0; r < RD; ++r) S2_READ(r)
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int d = i - ky;
-                    if (d >= 0 && d % S == 0 && d / S < NT) {
+                    if (!(S2_ABL & 8) && d >= 0 && d % S == 0 && d / S < NT) {
                         const int t = d / S;
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ky * 3 + kx], xh, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xo, acc[t], 0, 0, 0);
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
             // ---- epilogue: ReLU, split, 16-byte chunk stores ---------------------------------------
             const int rfl = relu_floor(p.relu);                  // branch-free (see sb.h)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < ((S2_ABL & 32) ? 1 : NT); ++t) {
                 float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = relu_opt(v[i], rfl);

@@ -188,7 +188,8 @@ struct Builder {
         c.dconvs.push_back(d);
         Op o;
         o.kind = OP_CONV; o.dconv = (int)c.dconvs.size() - 1; o.in = in; o.res = res; o.relu = relu; o.lane = lane;
-        o.out = tensor(s.cout, s.level, tap);
+        // ESAHRNET_TAP_ALL=1 (debugging): every convolution output becomes a named tap
+        o.out = tensor(s.cout, s.level, tap.empty() && !out_f32 && getenv("ESAHRNET_TAP_ALL") ? "conv:" + s.name : tap);
         const int idx = (int)c.ops.size();
         c.tensors[o.out].def = idx;
         use(in, idx); use(res, idx);

@@ -72,12 +72,74 @@ def scan(path, need=7):
     return found
 
 
+def scan_src_overwrite(path, window=16):
+    """VALU writes to a register that an MFMA issued fewer than `window` cycles earlier reads as SrcA/SrcB.
+    Written while chasing position-dependent garbage in tile columns 12..15 (round 1); it turned out that hipcc
+    reuses MFMA source registers 4-5 cycles after issue in every kernel of this library and the results are
+    right, i.e. the operands are latched at issue — kept as a diagnostic.  Cycle model: SALU / branch 1,
+    VALU / DS / VMEM issue 4, s_nop N -> N + 1.
+    -> list of (mfma index, cycles, offending instruction)"""
+    lines, labels = [], {}
+    for raw in open(path):
+        s = raw.strip()
+        if not s or s.startswith(";"):
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", s)
+        if m:
+            labels[m.group(1)] = len(lines)
+            continue
+        if s.startswith(".") or s.endswith(":"):
+            continue
+        lines.append(s)
+    found = []
+
+    def walk(start, src, cyc, depth, origin):
+        j = start
+        while j < len(lines) and cyc < window and depth < 4:
+            t = lines[j]
+            if t.startswith("s_nop"):
+                cyc += int(t.split()[1]) + 1
+            elif t.startswith("s_cbranch") or t.startswith("s_branch"):
+                tgt = t.split()[1]
+                if tgt in labels:
+                    walk(labels[tgt], src, cyc + 1, depth + 1, origin)
+                if t.startswith("s_branch"):
+                    return
+                cyc += 1
+            elif t.startswith("v_mfma"):
+                return                      # the pipe is busy for its 4 passes: nothing lands earlier
+            elif t.startswith("s_"):
+                cyc += 1
+            elif t.startswith(("ds_", "global_", "buffer_", "scratch_", "flat_")):
+                cyc += 4                    # results arrive a memory latency later
+            else:
+                parts = t.split(None, 1)
+                ops = [x.strip() for x in parts[1].split(",")] if len(parts) > 1 else []
+                dst = _regs(ops[0]) if ops else set()
+                if t.startswith("v_permlane") and len(ops) > 1:
+                    dst |= _regs(ops[1])
+                if dst & src:
+                    found.append((origin, cyc, t))
+                    return
+                cyc += 4
+            j += 1
+
+    for i, l in enumerate(lines):
+        if l.startswith("v_mfma"):
+            ops = [t.strip() for t in l.split(None, 1)[1].split(",")]
+            walk(i + 1, _regs(ops[1]) | _regs(ops[2]), 4, 0, i)
+    return found
+
+
 if __name__ == "__main__":
     bad = 0
-    for f in sys.argv[1:]:
+    for f in [a for a in sys.argv[1:] if not a.startswith("--")]:
         r = scan(f)
         for origin, waits, t in r:
             print(f"{f}: MFMA #{origin} result read after {waits} wait states: {t[:80]}")
+        if "--src-overwrite" in sys.argv:      # informational: hipcc does this everywhere and the hardware copes
+            for origin, cyc, t in scan_src_overwrite(f):
+                print(f"{f}: MFMA #{origin} source operand overwritten {cyc} cycles after issue: {t[:80]}")
         bad += len(r)
         print(f"{f}: {len(r)} hazard(s)")
     sys.exit(1 if bad else 0)
