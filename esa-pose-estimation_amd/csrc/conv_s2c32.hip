@@ -40,7 +40,8 @@ extern "C" int esa_debug_s2_wg(void* dst) {
 #endif
 
 // timing experiments (tools/ablate_any.sh): bit mask of parts compiled OUT — 1 X global loads, 2 X LDS writes,
-// 4 weight reloads, 8 MFMAs, 16 barriers, 32 epilogue + residual, 64 LDS operand reads.  0 in the product build.
+// 4 weight reloads, 8 MFMAs, 16 barriers, 32 epilogue (all but one row), 64 LDS operand reads, 128 residual.
+// 0 in the product build.
 #ifndef S2_ABL
 #define S2_ABL 0
 #endif
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
         // is folded into the accumulators, as 16-byte chunks (sb.h)
         constexpr int NH = NT >= 2 ? NT / 2 : 1;
         u32x4 rc[NH];
-        const bool do_res = !(S2_ABL & 32) && last_chunk && p.res != nullptr;
+        const bool do_res = !(S2_ABL & 128) && last_chunk && p.res != nullptr;
 #define S2_RES_LOAD(HALF)                                                                         \
         if (do_res) {                                                                             \
             _Pragma("unroll") for (int t = 0; t < NH; ++t) {                                      \
