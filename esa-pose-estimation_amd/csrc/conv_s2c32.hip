@@ -77,7 +77,9 @@ __device__ __forceinline__ int div_magic(int b, int d, uint32_t m) {
 // step s is consumed; the weight registers are a ring of three kx-thirds: as soon as phase kx of step s
 // is done, the (kx) third of step s+1 is loaded into the same registers (3 phases of cover, no extra
 // VGPRs).  Single-chunk layers whose cout slice does not change keep their weights for the whole launch.
-template <int S, int TH, int MW>
+// MH: multi-head launch (ConvParams::nheads > 1): the output tensor, its channel count and the ReLU flag depend on
+// the cout slice of the item.
+template <int S, int TH, int MW, bool MH = false>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, StreamGeo geo) {
     using S2C = ConvCfg<3, S, TH, 2>;
     constexpr int RG = 4 / MW;                  // row groups
@@ -91,8 +93,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
     const int mw = wave % MW, rg = wave / MW;
     const int G = gridDim.x;
     const int nchunks = p.Cinp >> 5;
-    const int pixb = p.Cinp * 4, opix = p.Coutp * 4;
-    const int ximg = p.H * p.W * pixb, yimg = p.OH * p.OW * opix;        // bytes per image (< 2^31, host-checked)
+    const int pixb = p.Cinp * 4;
+    int opix = p.Coutp * 4;                                              // (per item in a multi-head launch)
+    const int ximg = p.H * p.W * pixb;
+    int yimg = p.OH * p.OW * opix;                                       // bytes per image (< 2^31, host-checked)
     int item = xcd_contiguous(blockIdx.x, G);
     if (item >= geo.nitems) return;
 #ifdef S2_TRACE
@@ -101,7 +105,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
     if (wgon) g_s2_wg[blockIdx.x * 2] = wall_clock64();
 #endif
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (uint32_t)p.N * (uint32_t)ximg);
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, (uint32_t)p.N * (uint32_t)yimg);
+    __amdgpu_buffer_rsrc_t ry = make_rsrc(MH ? p.yh[0] : p.y, (uint32_t)p.N * (uint32_t)yimg);
+    int relu = p.relu;
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res : p.y, p.res ? (uint32_t)p.N * (uint32_t)yimg : 0u);
 
     // ---- staging map: thread -> (operand plane jst, tile pixel q0 + 32*it), fixed for the launch ----
@@ -204,7 +209,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
         prefetch(s_n, nch);
         TR(4)
         const bool reload = !(S2_ABL & 4) && more && (nchunks > 1 || nct != ct);
-        const int co = (ct * MW + mw) * 16 + g * 4;
+        int co = (ct * MW + mw) * 16 + g * 4;                   // cout of the lane's accumulator quad ...
+        if (MH) {                                               // ... inside its head's tensor
+            const int cb = (ct * MW + mw) * 16;                 // per wave: a 64-cout slice may span two heads
+            const int hsel = (cb >= p.hb[1] ? 1 : 0) + (p.nheads > 2 && cb >= p.hb[2] ? 1 : 0);
+            co -= p.hb[hsel];
+            opix = (p.hb[hsel + 1] - p.hb[hsel]) * 4;
+            yimg = p.OH * p.OW * opix;
+            ry = make_rsrc(p.yh[hsel], (uint32_t)p.N * (uint32_t)yimg);
+            relu = p.hrelu[hsel];
+        }
         if (c == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = bv;
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
 #undef S2_RES_ADD
         if (last_chunk) {
             // ---- epilogue: ReLU, split, 16-byte chunk stores ---------------------------------------
-            const int rfl = relu_floor(p.relu);                  // branch-free (see sb.h)
+            const int rfl = relu_floor(relu);                    // branch-free (see sb.h)
 #pragma unroll
             for (int t = 0; t < ((S2_ABL & 32) ? 1 : NT); ++t) {
                 float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
@@ -329,10 +343,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
 
 uint32_t magic_of(int d) { return (uint32_t)(0xffffffffull / (uint64_t)d); }
 
-template <int S, int TH, int MW>
+template <int S, int TH, int MW, bool MH = false>
 int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
     using S2C = ConvCfg<3, S, TH, 2>;
-    auto kern = conv_s2c32_kernel<S, TH, MW>;
+    auto kern = conv_s2c32_kernel<S, TH, MW, MH>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -377,6 +391,22 @@ bool conv_s2c32_supported(const ConvParams& p) {
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream) {
     if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
     return (p.Coutp % 64 == 0) ? launch_s2c32_t<2, 4, 4>(p, stream) : launch_s2c32_t<2, 4, 2>(p, stream);
+}
+
+bool conv_s2c32_multi_supported(const ConvParams& p) {
+    if (p.nheads < 2 || p.nheads > 3 || p.res || p.out_f32 || p.hb[0] != 0 || p.hb[p.nheads] != p.Coutp) return false;
+    if ((p.Cinp & 31) || p.Cinp < 32 || (long long)p.N * p.H * p.W * p.Cinp * 4 >= 0x7fffffffLL) return false;
+    for (int h = 0; h < p.nheads; ++h) {
+        const int c = p.hb[h + 1] - p.hb[h];
+        if (c <= 0 || (c & 31) || !p.yh[h] || (long long)p.N * p.OH * p.OW * c * 4 >= 0x7fffffffLL) return false;
+    }
+    return true;
+}
+
+// heads are multiples of 32 couts and a wave owns 16: every wave lies inside one head
+int launch_conv_s2c32_multi(const ConvParams& p, hipStream_t stream) {
+    if (!conv_s2c32_multi_supported(p)) return (int)hipErrorInvalidValue;
+    return (p.Coutp % 64 == 0) ? launch_s2c32_t<2, 4, 4, true>(p, stream) : launch_s2c32_t<2, 4, 2, true>(p, stream);
 }
 
 // the same scheme for stride 1: 64 couts x 8 rows per workgroup (wave = cout tile) where the layer has a

@@ -16,7 +16,18 @@ struct ConvParams {
     int Cinp, Coutp;    // multiples of 32
     int relu;
     int out_f32;        // 0: y is SB; 1: y is plain f32 NHWC [N][OH][OW][Coutp] (head terms t_b)
+    // multi-head form (stream kernel, stride 2 only): several convolutions of the SAME input evaluated in one launch —
+    // w / bias are the members' packed weights / biases concatenated along cout, Coutp their total, and head h
+    // (couts hb[h] .. hb[h+1]-1 of the concatenation, multiples of 32) goes to its own SB tensor yh[h] of
+    // hb[h+1]-hb[h] channels with its own ReLU flag.  nheads <= 1: the plain form above (y, relu).
+    int nheads;
+    char* yh[3];
+    int hb[4];
+    int hrelu[3];
 };
+// multi-head stride-2 3x3 (see ConvParams); every head must satisfy conv_s2c32_supported on its own
+bool conv_s2c32_multi_supported(const ConvParams& p);
+int launch_conv_s2c32_multi(const ConvParams& p, hipStream_t stream);
 // k in {1,3}, stride in {1,2}, pad = (k-1)/2.  Returns hipError_t as int.
 int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream);
 // name of the kernel launch_conv() runs for these parameters (only shapes / flags / res != nullptr are looked at)

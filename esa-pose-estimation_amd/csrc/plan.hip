@@ -106,6 +106,17 @@ struct Op {
     int nchan = 0;              // OP_ZERO: channels to clear;  OP_RESAMPLE/OP_APPLY/OP_MAPS: real channels
     int align = 0;              // OP_RESAMPLE: align_corners
     int alt = 0;                // 0: always; 1: head_fused path only; 2: head_fused2 path only (chosen per shape)
+    int multi = -1, mpos = 0;   // OP_CONV: member mpos of multi-head group `multi` (mpos 0 launches for all members)
+};
+
+// stride-2 3x3 convolutions of the SAME input tensor (the first links of the fuse-down chains of a stage), evaluated
+// by one multi-head launch of the stream kernel: the input is read once instead of once per chain
+struct Multi {
+    int n = 0;
+    int op[3] = {-1, -1, -1};   // op indices, consecutive: op[0] = leader
+    void* w = nullptr;          // device: the members' packed weights, concatenated along cout
+    float* bias = nullptr;
+    int coutp = 0;
 };
 
 struct ShapePlan {
@@ -115,6 +126,7 @@ struct ShapePlan {
     std::vector<int> lh, lw;    // resolution per level
     bool head2 = false;         // this shape runs the second-generation head (ops with alt == 2)
     bool head2_ulo = false;     // ... with the lo part of the interpolation weights
+    std::vector<char> multi_on; // per Multi: evaluated as one launch at this shape
 };
 
 }  // namespace
@@ -149,6 +161,7 @@ struct esahrnet_ctx {
     std::vector<char> needs_event;                    // per op: someone on another lane waits for it
     ShapePlan sp;
     int max_level = 0;
+    std::vector<Multi> multis;
 };
 
 namespace {
@@ -292,7 +305,71 @@ struct Builder {
     }
 };
 
+// Post-pass over the op list: find the stride-2 3x3 convolutions that share their input and make each such group
+// consecutive (moving a member EARLIER is always legal: its only input is defined before the group's first member).
+void group_multihead(esahrnet_ctx& c) {
+    if (getenv("ESAHRNET_NO_MULTIHEAD") || c.nlanes > 1) return;
+    auto eligible = [&](const Op& o) {
+        if (o.kind != OP_CONV || o.res >= 0 || o.alt != 0 || o.multi >= 0) return false;
+        const DevConv& d = c.dconvs[o.dconv];
+        const ConvSpec& s = c.specs[d.spec];
+        return s.k == 3 && s.stride == 2 && !d.out_f32 && d.c0 == 0 && d.c1 == s.cin && d.perm.empty() && d.use_bias;
+    };
+    std::vector<Op> ops = c.ops;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        if (!eligible(ops[i])) continue;
+        std::vector<size_t> members{i};
+        for (size_t j = i + 1; j < ops.size() && members.size() < 3; ++j)
+            if (eligible(ops[j]) && ops[j].in == ops[i].in) members.push_back(j);
+        if (members.size() < 2) continue;
+        // measured (W32, batch 32): worth it only where the shared input is the big 32/48-channel branch AND the
+        // heads add up to whole 64-cout workgroup slices (stage 4: 53.4 -> 40.8 us); 96 couts on 32-cout slices
+        // (stage 3: 40.1 -> 45.2 us) and the 64-channel input (31.8 -> 32.6 us) are not
+        {
+            int tot = 0;
+            for (size_t k : members) tot += c.dconvs[ops[k].dconv].coutp;
+            if (tot % 64 != 0 || c.dconvs[ops[i].dconv].cinp > 64 || c.tensors[ops[i].in].level > 1) continue;
+        }
+        const int mi = (int)c.multis.size();
+        Multi m;
+        m.n = (int)members.size();
+        // pull the members up behind the leader (back to front so that the indices stay valid)
+        std::vector<Op> pulled;
+        for (size_t k = members.size(); k-- > 1;) {
+            pulled.insert(pulled.begin(), ops[members[k]]);
+            ops.erase(ops.begin() + members[k]);
+        }
+        ops.insert(ops.begin() + i + 1, pulled.begin(), pulled.end());
+        for (int k = 0; k < m.n; ++k) {
+            ops[i + k].multi = mi;
+            ops[i + k].mpos = k;
+            m.op[k] = (int)(i + k);
+            m.coutp += c.dconvs[ops[i + k].dconv].coutp;
+        }
+        c.multis.push_back(m);
+    }
+    c.ops = ops;
+    // op indices moved: recompute first definition / last use of every tensor and the head2 op index
+    for (Tensor& t : c.tensors) { t.def = -1; t.last = -1; }
+    c.head2_op = -1;
+    for (size_t k = 0; k < c.ops.size(); ++k) {
+        const Op& o = c.ops[k];
+        if (o.kind == OP_HEAD2) c.head2_op = (int)k;
+        if (o.out >= 0 && c.tensors[o.out].def < 0) c.tensors[o.out].def = (int)k;
+        auto use = [&](int t) { if (t >= 0) c.tensors[t].last = std::max(c.tensors[t].last, (int)k); };
+        use(o.in); use(o.res);
+        for (int t = 0; t < 4; ++t) use(o.terms[t]);
+    }
+}
+
+int build_plan_ops(esahrnet_ctx& c);
 int build_plan(esahrnet_ctx& c) {
+    if (build_plan_ops(c)) return 1;
+    group_multihead(c);
+    return 0;
+}
+
+int build_plan_ops(esahrnet_ctx& c) {
     const esahrnet_cfg& g = c.cfg;
     Builder B(c);
     const int sw = g.stem_width;
@@ -553,6 +630,21 @@ bool head2_for_shape(const esahrnet_ctx& c, const std::vector<int>& lh, const st
 }
 
 // first-fit interval allocator over op order; tensors die after their last use
+// is this multi-head group evaluated as ONE launch at this shape?  (depends on the shape only through the kernel's limits)
+bool multi_on_for(const esahrnet_ctx& c, const Multi& m, int n, const std::vector<int>& lh, const std::vector<int>& lw) {
+    esa::ConvParams q{};
+    const Op& o0 = c.ops[m.op[0]];
+    const Tensor& ti = c.tensors[o0.in];
+    const Tensor& to = c.tensors[o0.out];
+    q.N = n; q.H = lh[ti.level]; q.W = lw[ti.level]; q.OH = lh[to.level]; q.OW = lw[to.level];
+    q.Cinp = ti.Cp; q.Coutp = m.coutp; q.nheads = m.n;
+    for (int k = 0; k < m.n; ++k) {
+        q.hb[k + 1] = q.hb[k] + c.dconvs[c.ops[m.op[k]].dconv].coutp;
+        q.yh[k] = reinterpret_cast<char*>(const_cast<esahrnet_ctx*>(&c));      // only tested against nullptr
+    }
+    return esa::conv_s2c32_multi_supported(q);
+}
+
 int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
     if (c.sp.n == n && c.sp.h == h && c.sp.w == w && c.sp.keep == c.keep) return 0;
     if (check_shape(c, n, h, w)) return 1;
@@ -561,6 +653,8 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
     level_dims(c, h, w, sp.lh, sp.lw);
     sp.head2 = head2_for_shape(c, sp.lh, sp.lw, &sp.head2_ulo);
     const int active_alt = sp.head2 ? 2 : 1;
+    sp.multi_on.assign(c.multis.size(), 0);
+    for (size_t mi = 0; mi < c.multis.size(); ++mi) sp.multi_on[mi] = multi_on_for(c, c.multis[mi], n, sp.lh, sp.lw) ? 1 : 0;
     struct Free { size_t off, len; };
     std::vector<Free> free_list;
     size_t top = 0;
@@ -673,6 +767,11 @@ void free_weights(esahrnet_ctx& c) {
     for (void** p : {&c.head_w0, &c.head_w3, &c.final_wpk})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (AuxSpec& a : c.aux) if (a.dev) { (void)hipFree(a.dev); a.dev = nullptr; }
+    for (Multi& m : c.multis) {
+        if (m.w) (void)hipFree(m.w);
+        if (m.bias) (void)hipFree(m.bias);
+        m.w = nullptr; m.bias = nullptr;
+    }
     for (float** p : {&c.stemraw_w, &c.stemraw_b}) if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (hipEvent_t& e : c.op_event) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     c.op_event.clear();
@@ -808,6 +907,23 @@ int esahrnet_commit(esahrnet_handle h) {
         std::vector<float> bias(d.coutp, 0.f);
         if (d.use_bias) std::copy(s.b.begin(), s.b.end(), bias.begin());
         if (upload(bias, reinterpret_cast<void**>(&d.bias))) return 1;
+    }
+    for (Multi& m : h->multis) {     // members' packed weights / biases back to back (cout-tile major packing)
+        size_t wbytes = 0;
+        for (int k = 0; k < m.n; ++k) {
+            const DevConv& d = h->dconvs[h->ops[m.op[k]].dconv];
+            wbytes += esa::packed_weight_bytes(d.coutp, d.cinp, 3);
+        }
+        HIP_OK(hipMalloc(&m.w, wbytes));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&m.bias), (size_t)m.coutp * sizeof(float)));
+        size_t wo = 0, bo = 0;
+        for (int k = 0; k < m.n; ++k) {
+            const DevConv& d = h->dconvs[h->ops[m.op[k]].dconv];
+            const size_t wb = esa::packed_weight_bytes(d.coutp, d.cinp, 3);
+            HIP_OK(hipMemcpy(static_cast<char*>(m.w) + wo, d.w, wb, hipMemcpyDeviceToDevice));
+            HIP_OK(hipMemcpy(m.bias + bo, d.bias, (size_t)d.coutp * sizeof(float), hipMemcpyDeviceToDevice));
+            wo += wb; bo += d.coutp;
+        }
     }
     {   // stem: [cout/8][cin][9][8]
         const ConvSpec& s = h->specs[h->spec_stem];
@@ -1027,6 +1143,24 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 const Tensor& ti = h->tensors[o.in];
                 const Tensor& to = h->tensors[o.out];
                 if (ti.Cp != d.cinp || to.Cp != d.coutp) return fail("plan bug: channel mismatch at %s", s.name.c_str());
+                if (o.multi >= 0 && sp.multi_on[o.multi]) {
+                    if (o.mpos > 0) break;                      // evaluated by the group's leader
+                    const Multi& m = h->multis[o.multi];
+                    esa::ConvParams p{};
+                    p.x = T(o.in);
+                    p.w = static_cast<const uint4*>(m.w); p.bias = m.bias;
+                    p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level];
+                    p.OH = sp.lh[to.level]; p.OW = sp.lw[to.level];
+                    p.Cinp = d.cinp; p.Coutp = m.coutp; p.nheads = m.n;
+                    for (int k = 0; k < m.n; ++k) {
+                        const Op& ok = h->ops[m.op[k]];
+                        p.yh[k] = T(ok.out);
+                        p.hb[k + 1] = p.hb[k] + h->dconvs[ok.dconv].coutp;
+                        p.hrelu[k] = ok.relu;
+                    }
+                    rc = esa::launch_conv_s2c32_multi(p, stream);
+                    break;
+                }
                 esa::ConvParams p{};
                 p.x = T(o.in); p.y = T(o.out); p.res = o.res >= 0 ? T(o.res) : nullptr;
                 p.w = static_cast<const uint4*>(d.w); p.bias = d.bias;
@@ -1216,6 +1350,27 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             const DevConv& d = h->dconvs[o.dconv];
             const ConvSpec& s = h->specs[d.spec];
             const Tensor& to = h->tensors[o.out];
+            if (o.multi >= 0 && multi_on_for(*h, h->multis[o.multi], n, lh, lw)) {
+                const Multi& m = h->multis[o.multi];
+                if (o.mpos > 0) {        // no launch of its own
+                    snprintf(out->label, sizeof out->label, "%s (in the multi-head launch above)", s.name.c_str());
+                    break;
+                }
+                snprintf(out->kernel, sizeof out->kernel, m.coutp % 64 == 0 ? "conv_s2c32_kernel<2, 4, 4, true>" : "conv_s2c32_kernel<2, 4, 2, true>");
+                std::string lab;
+                out->bytes = tbytes(o.in);
+                for (int k = 0; k < m.n; ++k) {
+                    const Op& ok = h->ops[m.op[k]];
+                    const DevConv& dk = h->dconvs[ok.dconv];
+                    const ConvSpec& sk = h->specs[dk.spec];
+                    const Tensor& tk = h->tensors[ok.out];
+                    lab += (k ? " + " : "") + sk.name;
+                    out->flops += 2.0 * n * lh[tk.level] * lw[tk.level] * sk.cout * sk.cin * 9.0;
+                    out->bytes += tbytes(ok.out) + (double)esa::packed_weight_bytes(dk.coutp, dk.cinp, 3);
+                }
+                snprintf(out->label, sizeof out->label, "%s", lab.c_str());
+                break;
+            }
             {
                 const Tensor& ti = h->tensors[o.in];
                 esa::ConvParams q{};
