@@ -313,7 +313,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
                 const uint4 ch = quad_to_chunk(hi, lo);
                 const u32x4 cv = {ch.x, ch.y, ch.z, ch.w};
                 const uint32_t so_ = t < nrows ? o0 + (uint32_t)(t * orow) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(cv, ry, (int)so_, yso, 0);
+                // The image base goes into the VECTOR offset, the scalar offset stays the constant 0: gfx950 reads the
+                // data registers of a 16-byte buffer store late (lanes 12..15 of every row of 16), so the instruction
+                // behind it must not overwrite them — and hipcc 7.2 pads that hazard only for stores WITHOUT an
+                // soffset register (tools/ubench/store_data_war.hip; with `yso` as soffset the epilogue of the next
+                // row landed in this row's columns 12..15 whenever the scheduler put it right behind the store).
+                __builtin_amdgcn_raw_buffer_store_b128(cv, ry, (int)(so_ + (uint32_t)yso), 0, 0);
             }
             TR(8)
 #ifdef S2_TRACE

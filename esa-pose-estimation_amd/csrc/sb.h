@@ -65,10 +65,13 @@ __device__ __forceinline__ float relu1(float v) {
 // Keep it branch-free on purpose: with `if (relu) {...}` right behind the last MFMA of an accumulator, hipcc
 // (ROCm 7.2) pads the MFMA -> VALU read hazard with s_nop only on the taken path, and the fall-through path
 // reads the accumulator registers too early (observed: wrong low-order bits in the first two channels).
+// (readfirstlane hides the two-valued origin of the floor: otherwise hipcc turns the max back into max-against-0
+// plus a select)
 __device__ __forceinline__ int relu_floor(int relu) { return relu ? 0 : (int)0x80000000; }
 __device__ __forceinline__ float relu_opt(float v, int floor) {
-    const int b = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, b > floor ? b : floor);
+    // __builtin_elementwise_max keeps it ONE v_max_i32; written as `b > floor ? b : floor` hipcc emits
+    // v_cmp + s_nop + v_cndmask per element (12 instead of 4 instructions per accumulator quad)
+    return __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, v), floor));
 }
 
 // 4 floats -> 8 bytes of hi bf16 + 8 bytes of lo bf16

@@ -72,6 +72,64 @@ def scan(path, need=7):
     return found
 
 
+def scan_store_data(path, need=2):
+    """VALU writes to a data register of a 12- or 16-byte store fewer than `need` wait states behind it.  gfx950 reads the data of such a store late for lanes 12..15 of every row of 16
+    (tools/ubench/store_data_war.hip, store_war2.hip: buffer stores need 1 wait state, global stores 2); hipcc 7.2 pads
+    global / flat stores and buffer stores with an IMMEDIATE soffset, but not buffer stores whose soffset is an SGPR.
+    -> list of (store index, wait states, offending instruction)"""
+    lines, labels = [], {}
+    for raw in open(path):
+        s = raw.strip()
+        if not s or s.startswith(";"):
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", s)
+        if m:
+            labels[m.group(1)] = len(lines)
+            continue
+        if s.startswith(".") or s.endswith(":"):
+            continue
+        lines.append(s)
+    found = []
+
+    def walk(start, data, ws, depth, origin):
+        j = start
+        while j < len(lines) and ws < need and depth < 4:
+            t = lines[j]
+            if t.startswith("s_nop"):
+                ws += int(t.split()[1]) + 1
+            elif t.startswith("s_cbranch") or t.startswith("s_branch"):
+                tgt = t.split()[1]
+                if tgt in labels:
+                    walk(labels[tgt], data, ws + 1, depth + 1, origin)
+                if t.startswith("s_branch"):
+                    return
+                ws += 1
+            elif t.startswith("s_"):
+                ws += 1
+            else:
+                parts = t.split(None, 1)
+                ops = [x.strip() for x in parts[1].split(",")] if len(parts) > 1 else []
+                # memory instructions write their destinations a latency later, not at issue: they only count as time
+                is_mem = t.startswith(("ds_", "buffer_", "global_", "flat_", "scratch_"))
+                dst = set() if is_mem or not ops else _regs(ops[0])
+                if t.startswith("v_permlane") and len(ops) > 1:
+                    dst |= _regs(ops[1])
+                if dst & data:
+                    found.append((origin, ws, t))
+                    return
+                ws += 1
+            j += 1
+
+    for i, l in enumerate(lines):
+        m = re.match(r"(buffer|global|flat|scratch)_store_dwordx[34]\s+(.*)", l)
+        if not m:
+            continue
+        ops = [t.strip() for t in m.group(2).split(",")]
+        data = _regs(ops[0]) if m.group(1) == "buffer" else _regs(ops[1])      # buffer: vdata first; global/flat: vaddr, vdata
+        walk(i + 1, data, 0, 0, i)
+    return found
+
+
 def scan_src_overwrite(path, window=16):
     """VALU writes to a register that an MFMA issued fewer than `window` cycles earlier reads as SrcA/SrcB.
     Written while chasing position-dependent garbage in tile columns 12..15 (round 1); it turned out that hipcc
@@ -137,6 +195,10 @@ if __name__ == "__main__":
         r = scan(f)
         for origin, waits, t in r:
             print(f"{f}: MFMA #{origin} result read after {waits} wait states: {t[:80]}")
+        r3 = scan_store_data(f)
+        for origin, ws, t in r3:
+            print(f"{f}: store #{origin}: data register overwritten {ws} wait state(s) later: {t[:80]}")
+        r = r + r3
         if "--src-overwrite" in sys.argv:      # informational: hipcc does this everywhere and the hardware copes
             for origin, cyc, t in scan_src_overwrite(f):
                 print(f"{f}: MFMA #{origin} source operand overwritten {cyc} cycles after issue: {t[:80]}")

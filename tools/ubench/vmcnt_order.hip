@@ -13,6 +13,7 @@ __global__ __launch_bounds__(256) void k(const unsigned* cold, const unsigned* h
     __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cold, 0, (int)(cold_words * 4u), 0x00020000);
     __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)hot, 0, 4096 * 4, 0x00020000);
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sink, 0, 1 << 24, 0x00020000);
+    __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)hot, 0, 0, 0x00020000);
     int bad = 0;
     unsigned seed = gid * 2654435761u + 12345u;
     for (int it = 0; it < iters; ++it) {
@@ -38,7 +39,23 @@ __global__ __launch_bounds__(256) void k(const unsigned* cold, const unsigned* h
             asm volatile("v_mov_b32 %0, 0xdeadbeef\n s_nop 1\n global_load_dword %0, %2, off\n global_load_dword %1, %3, off\n"
                          "s_waitcnt vmcnt(1)\n v_mov_b32 %0, %0\n s_waitcnt vmcnt(0)\n"
                          : "=&v"(got), "=&v"(other) : "v"(cptr), "v"(hptr) : "memory");
-        else                  // buffer cold, buffer hot
+        else if (MODE >= 5) { // buffer cold, then an OUT-OF-RANGE buffer op: 5 load all lanes, 6 load odd lanes, 7 store all lanes, 8 load via descriptor with 0 records
+            const unsigned oob = 0x80000000u;
+            const unsigned yoff = MODE == 6 ? ((lane & 1) ? oob : hoff) : oob;
+            if (MODE == 7)
+                asm volatile("v_mov_b32 %0, 0xdeadbeef\n v_mov_b32 %1, 0\n s_nop 1\n buffer_load_dword %0, %2, %3, 0 offen\n buffer_store_dword %1, %4, %5, 0 offen\n"
+                             "s_waitcnt vmcnt(1)\n v_mov_b32 %0, %0\n s_waitcnt vmcnt(0)\n"
+                             : "=&v"(got), "=&v"(other) : "v"(coff), "s"(rc), "v"(yoff), "s"(rs) : "memory");
+            else if (MODE == 8)
+                asm volatile("v_mov_b32 %0, 0xdeadbeef\n s_nop 1\n buffer_load_dword %0, %2, %3, 0 offen\n buffer_load_dword %1, %4, %5, 0 offen\n"
+                             "s_waitcnt vmcnt(1)\n v_mov_b32 %0, %0\n s_waitcnt vmcnt(0)\n"
+                             : "=&v"(got), "=&v"(other) : "v"(coff), "s"(rc), "v"(hoff), "s"(rz) : "memory");
+            else
+                asm volatile("v_mov_b32 %0, 0xdeadbeef\n s_nop 1\n buffer_load_dword %0, %2, %3, 0 offen\n buffer_load_dword %1, %4, %5, 0 offen\n"
+                             "s_waitcnt vmcnt(1)\n v_mov_b32 %0, %0\n s_waitcnt vmcnt(0)\n"
+                             : "=&v"(got), "=&v"(other) : "v"(coff), "s"(rc), "v"(yoff), "s"(rh) : "memory");
+            if (MODE == 8 && other != 0) bad += 1 << 20;      // an empty descriptor must read zeros
+        } else                // buffer cold, buffer hot
             asm volatile("v_mov_b32 %0, 0xdeadbeef\n s_nop 1\n buffer_load_dword %0, %2, %3, 0 offen\n buffer_load_dword %1, %4, %5, 0 offen\n"
                          "s_waitcnt vmcnt(1)\n v_mov_b32 %0, %0\n s_waitcnt vmcnt(0)\n"
                          : "=&v"(got), "=&v"(other) : "v"(coff), "s"(rc), "v"(hoff), "s"(rh) : "memory");
@@ -56,14 +73,20 @@ int main() {
     fill<<<4096, 256>>>(cold, cold_words); fill<<<16, 256>>>(hot, 4096);
     CK(hipDeviceSynchronize());
     const char* names[] = {"buffer_load cold ; global_load hot", "global_load cold ; buffer_load hot", "buffer_load cold ; buffer_store",
-                           "global_load cold ; global_load hot", "buffer_load cold ; buffer_load hot"};
-    for (int mode = 0; mode < 5; ++mode) {
+                           "global_load cold ; global_load hot", "buffer_load cold ; buffer_load hot",
+                           "buffer_load cold ; buffer_load OUT OF RANGE", "buffer_load cold ; buffer_load half out of range",
+                           "buffer_load cold ; buffer_store OUT OF RANGE", "buffer_load cold ; load via 0-record desc"};
+    for (int mode = 0; mode < 9; ++mode) {
         CK(hipMemset(dbad, 0, 4));
         if (mode == 0) k<0><<<2048, 256>>>(cold, hot, sink, dbad, 200, (unsigned)cold_words);
         if (mode == 1) k<1><<<2048, 256>>>(cold, hot, sink, dbad, 200, (unsigned)cold_words);
         if (mode == 2) k<2><<<2048, 256>>>(cold, hot, sink, dbad, 200, (unsigned)cold_words);
         if (mode == 3) k<3><<<2048, 256>>>(cold, hot, sink, dbad, 200, (unsigned)cold_words);
         if (mode == 4) k<4><<<2048, 256>>>(cold, hot, sink, dbad, 200, (unsigned)cold_words);
+        if (mode == 5) k<5><<<2048, 256>>>(cold, hot, sink, dbad, 200, (unsigned)cold_words);
+        if (mode == 6) k<6><<<2048, 256>>>(cold, hot, sink, dbad, 200, (unsigned)cold_words);
+        if (mode == 7) k<7><<<2048, 256>>>(cold, hot, sink, dbad, 200, (unsigned)cold_words);
+        if (mode == 8) k<8><<<2048, 256>>>(cold, hot, sink, dbad, 200, (unsigned)cold_words);
         int h; CK(hipMemcpy(&h, dbad, 4, hipMemcpyDeviceToHost));
         printf("%-40s then vmcnt(1): %d stale reads of the older load out of %d\n", names[mode], h, 2048 * 256 * 200);
     }
