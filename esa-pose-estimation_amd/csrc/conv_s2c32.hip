@@ -26,6 +26,7 @@
 #include "conv_cfg.h"
 #include "kernels.h"
 #include "sb.h"
+#include <type_traits>
 
 #ifdef S2_TRACE
 // debug build only (tools/trace_s2.py, -DS2_TRACE=<Cinp>): per-wave cycle stamps of the stream kernel's phases
@@ -44,6 +45,9 @@ extern "C" int esa_debug_s2_wg(void* dst) {
 // 0 in the product build.
 #ifndef S2_ABL
 #define S2_ABL 0
+#endif
+#ifndef S2_INPHASE
+#define S2_INPHASE 1      // epilogue rows inside the last MFMA phase (0: after it)
 #endif
 #ifndef S2_RD
 #define S2_RD 2          // LDS read-ahead distance (input rows)
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
     constexpr int RG = 4 / MW;                  // row groups
     constexpr int NT = TH / RG;                 // output rows per wave
     constexpr int ROWS = (NT - 1) * S + 3;      // input rows a wave touches
-    constexpr int RD = (S == 1 && TH == 16) ? 0 : S2_RD;     // the 16-row tile has no registers to spare
+    constexpr int RD = S == 1 ? (TH == 16 ? 0 : 1) : (MW == 4 ? 1 : S2_RD);  // as many rows as the register budget allows
+    constexpr bool INPHASE = S2_INPHASE && !(S == 1 && TH == 16);  // (the 16-row tile has no registers to spare)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -228,31 +233,49 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
         const uint32_t o0 = rox < p.OW ? (uint32_t)((roy * p.OW + rox) * opix + chunk_ofs(co, g)) : OOB;
         const int orow = p.OW * opix, yso = n * yimg;
         const int nrows = p.OH - roy;                                   // rows t < nrows exist
-        // residual (last chunk only): two halves of the wave's rows, each loaded a phase or two before it
-        // is folded into the accumulators, as 16-byte chunks (sb.h)
+        // residual (last chunk only): the first half of the wave's rows is loaded at the start of the step and folded
+        // into the accumulators after the second phase; the second half is loaded then and folded in by the row's
+        // epilogue.  16-byte chunks (sb.h).
         constexpr int NH = NT >= 2 ? NT / 2 : 1;
         u32x4 rc[NH];
+        const int rfl = relu_floor(relu);                        // branch-free optional ReLU (see sb.h)
         const bool do_res = !(S2_ABL & 128) && last_chunk && p.res != nullptr;
-#define S2_RES_LOAD(HALF)                                                                         \
-        if (do_res) {                                                                             \
-            _Pragma("unroll") for (int t = 0; t < NH; ++t) {                                      \
-                const int tt = (HALF) * NH + t;                                                   \
-                const uint32_t ro_ = (tt < NT && tt < nrows) ? o0 + (uint32_t)(tt * orow) : OOB;  \
-                rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ro_, yso, 0);              \
-            }                                                                                     \
-        }
-#define S2_RES_ADD(HALF)                                                                          \
-        if (do_res) {                                                                             \
-            _Pragma("unroll") for (int t = 0; t < NH; ++t)                                        \
-                if ((HALF) * NH + t < NT) {                                                       \
-                    uint2 rh_, rl_;                                                               \
-                    chunk_to_quad(make_uint4(rc[t][0], rc[t][1], rc[t][2], rc[t][3]), rh_, rl_);  \
-                    float r_[4];                                                                  \
-                    join4(rh_, rl_, r_);                                                          \
-                    _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[(HALF) * NH + t][i] += r_[i]; \
-                }                                                                                 \
-        }
-        S2_RES_LOAD(0)
+        auto res_load = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < NH; ++t) {
+                const int tt = half * NH + t;
+                const uint32_t ro_ = (tt < NT && tt < nrows) ? o0 + (uint32_t)(tt * orow) : OOB;
+                rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ro_, yso, 0);
+            }
+        };
+        auto res_of = [&](int t, float r_[4]) __attribute__((always_inline)) {
+            uint2 rh_, rl_;
+            chunk_to_quad(make_uint4(rc[t][0], rc[t][1], rc[t][2], rc[t][3]), rh_, rl_);
+            join4(rh_, rl_, r_);
+        };
+        auto epilogue_row = [&](int t, auto res_c) __attribute__((always_inline)) {
+            float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+            if (decltype(res_c)::value && NT >= 2 && t >= NH) {
+                float r_[4];
+                res_of(t - NH, r_);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += r_[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = relu_opt(v[i], rfl);
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            const uint4 ch = quad_to_chunk(hi, lo);
+            const u32x4 cv = {ch.x, ch.y, ch.z, ch.w};
+            const uint32_t so_ = t < nrows ? o0 + (uint32_t)(t * orow) : OOB;
+            // The image base goes into the VECTOR offset, the scalar offset stays the constant 0: gfx950 reads the
+            // data registers of a 16-byte buffer store late (lanes 12..15 of every row of 16), so the instruction
+            // behind it must not overwrite them — and hipcc 7.2 pads that hazard only for stores WITHOUT an
+            // soffset register (tools/ubench/store_data_war.hip; with `yso` as soffset the epilogue of the next
+            // row landed in this row's columns 12..15 whenever the scheduler put it right behind the store).
+            __builtin_amdgcn_raw_buffer_store_b128(cv, ry, (int)(so_ + (uint32_t)yso), 0, 0);
+        };
+        if (do_res) res_load(0);
         bf16x8 fh[RD + 1], fo[RD + 1];
 #define S2_READ(IDX)                                                                              \
         {                                                                                         \
@@ -265,10 +288,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
                 fo[(IDX) % (RD + 1)] = wl[(IDX) % 9];                                             \
             }                                                                                     \
         }
-#pragma unroll
-        for (int r = 0; r < RD; ++r) S2_READ(r)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+        // one kx phase.  The third phase of a last chunk is straight-line code of its own: the epilogue of output
+        // row t (ReLU, split, chunk swap, store: ~20 VALU instructions) is emitted one input row after the row's
+        // last MFMA and rides in the issue shadow of the next row's MFMAs instead of running after the phase with
+        // the matrix pipe idle (measured: the epilogues were 13 % of a layer, 6 % of the forward).
+        auto phase = [&](auto kx_c, auto last_c, auto res_c) __attribute__((always_inline)) {
+            constexpr int kx = decltype(kx_c)::value;
+            constexpr bool EPI = INPHASE && decltype(last_c)::value && kx == 2 && !(S2_ABL & 32);
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) {
                 const int idx = kx * ROWS + i;
@@ -276,6 +302,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
                     S2_READ(idx + RD)
                     __builtin_amdgcn_sched_barrier(0);       // keep the read ahead of this row's MFMAs
                 }
+                // output row (i - 3) / S got its last MFMA one input row ago
+                if (EPI && i >= 3 && (i - 3) % S == 0 && (i - 3) / S < NT) epilogue_row((i - 3) / S, res_c);
                 const bf16x8 xh = fh[idx % (RD + 1)];
                 const bf16x8 xo = fo[idx % (RD + 1)];
 #pragma unroll
@@ -289,37 +317,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
                     }
                 }
             }
-            if (reload) S2_LOAD_W(nct, nch, kx)     // this third is free: refill it for step s+1
-            if (kx == 1) {
-                S2_RES_ADD(0)
-                if (NT >= 2) S2_RES_LOAD(1)
+            if (EPI) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (t * S + 3 > ROWS - 1) epilogue_row(t, res_c);      // rows finished by the final input rows
             }
-            if (kx == 2 && NT >= 2) S2_RES_ADD(1)
-            TR(5 + kx)
+        };
+#pragma unroll
+        for (int r = 0; r < RD; ++r) S2_READ(r)
+        phase(std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
+        if (reload) S2_LOAD_W(nct, nch, 0)          // this third is free: refill it for step s+1
+        TR(5)
+        phase(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{});
+        if (reload) S2_LOAD_W(nct, nch, 1)
+        if (do_res) {
+#pragma unroll
+            for (int t = 0; t < NH; ++t) {
+                float r_[4];
+                res_of(t, r_);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] += r_[i];
+            }
+            if (NT >= 2) res_load(1);
         }
+        TR(6)
+        if (!last_chunk) phase(std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{});
+        else if (do_res) phase(std::integral_constant<int, 2>{}, std::true_type{}, std::true_type{});
+        else phase(std::integral_constant<int, 2>{}, std::true_type{}, std::false_type{});
+        if (reload) S2_LOAD_W(nct, nch, 2)
+        TR(7)
 #undef S2_READ
-#undef S2_RES_LOAD
-#undef S2_RES_ADD
-        if (last_chunk) {
-            // ---- epilogue: ReLU, split, 16-byte chunk stores ---------------------------------------
-            const int rfl = relu_floor(relu);                    // branch-free (see sb.h)
+        if (last_chunk && !(INPHASE && !(S2_ABL & 32))) {
 #pragma unroll
             for (int t = 0; t < ((S2_ABL & 32) ? 1 : NT); ++t) {
-                float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = relu_opt(v[i], rfl);
-                uint2 hi, lo;
-                split4(v, hi, lo);
-                const uint4 ch = quad_to_chunk(hi, lo);
-                const u32x4 cv = {ch.x, ch.y, ch.z, ch.w};
-                const uint32_t so_ = t < nrows ? o0 + (uint32_t)(t * orow) : OOB;
-                // The image base goes into the VECTOR offset, the scalar offset stays the constant 0: gfx950 reads the
-                // data registers of a 16-byte buffer store late (lanes 12..15 of every row of 16), so the instruction
-                // behind it must not overwrite them — and hipcc 7.2 pads that hazard only for stores WITHOUT an
-                // soffset register (tools/ubench/store_data_war.hip; with `yso` as soffset the epilogue of the next
-                // row landed in this row's columns 12..15 whenever the scheduler put it right behind the store).
-                __builtin_amdgcn_raw_buffer_store_b128(cv, ry, (int)(so_ + (uint32_t)yso), 0, 0);
+                if (do_res) epilogue_row(t, std::true_type{});
+                else epilogue_row(t, std::false_type{});
             }
+        }
+        if (last_chunk) {
             TR(8)
 #ifdef S2_TRACE
             if (ton && !more) {
