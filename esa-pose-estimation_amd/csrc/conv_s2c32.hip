@@ -89,8 +89,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
     constexpr int RG = 4 / MW;                  // row groups
     constexpr int NT = TH / RG;                 // output rows per wave
     constexpr int ROWS = (NT - 1) * S + 3;      // input rows a wave touches
-    constexpr int RD = S == 1 ? (TH == 16 ? 0 : 1) : (MW == 4 ? 1 : S2_RD);  // as many rows as the register budget allows
-    constexpr bool INPHASE = S2_INPHASE && !(S == 1 && TH == 16);  // (the 16-row tile has no registers to spare)
+    constexpr int RD = (S == 1 && MW == 2) ? S2_RD : 1;      // as many rows as the register budget allows
+    constexpr bool INPHASE = S2_INPHASE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -450,11 +450,12 @@ int launch_conv_s2c32_multi(const ConvParams& p, hipStream_t stream) {
 }
 
 // the same scheme for stride 1: 64 couts x 8 rows per workgroup (wave = cout tile) where the layer has a
-// multiple of 64 couts, else 32 couts x 16 rows (wave = cout tile x 8 rows)
+// multiple of 64 couts, else 32 couts x 8 rows (wave = cout tile x 4 rows; the 16-row tile of earlier builds sat at
+// 256 VGPRs and was 4-14 % slower)
 int launch_conv_s1w(const ConvParams& p, hipStream_t stream) {
     if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
     if (p.Coutp % 64 == 0) return launch_s2c32_t<1, 8, 4>(p, stream);
-    return launch_s2c32_t<1, 16, 2>(p, stream);
+    return launch_s2c32_t<1, 8, 2>(p, stream);
 }
 
 }  // namespace esa
