@@ -89,7 +89,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
     constexpr int RG = 4 / MW;                  // row groups
     constexpr int NT = TH / RG;                 // output rows per wave
     constexpr int ROWS = (NT - 1) * S + 3;      // input rows a wave touches
-    constexpr int RD = (S == 1 && MW == 2) ? S2_RD : 1;      // as many rows as the register budget allows
+#ifndef S2_RD84
+#define S2_RD84 1
+#endif
+    constexpr int RD = (S == 1 && MW == 2) ? S2_RD : (S == 1 && MW == 4) ? S2_RD84 : 1;   // as many rows as the register budget allows
     constexpr bool INPHASE = S2_INPHASE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
