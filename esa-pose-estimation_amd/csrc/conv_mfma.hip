@@ -553,7 +553,10 @@ Choice choose_conv(const ConvParams& p, int k, int stride) {
         const long long items_per_image = (long long)((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 32);
         // (very deep contractions amortise the ring's prologue and share each weight chunk between four waves
         // through LDS: the 480 -> 480 3x3 of seg_hrnet3 runs 436 TFLOP/s on the ring, 400 on the stream kernel)
-        if (ESA_S1W && items_per_image >= 8 && p.Cinp <= 256 && conv_s2c32_supported(p)) return C_STREAM_S1;
+#ifndef ESA_S1W_MAXC
+#define ESA_S1W_MAXC 256
+#endif
+        if (ESA_S1W && items_per_image >= 8 && p.Cinp <= ESA_S1W_MAXC && conv_s2c32_supported(p)) return C_STREAM_S1;
         // deep, small-resolution layers have too few 16x16 tiles to fill 2 workgroups on every CU: halve the
         // tile height there
         if (p.Cinp > 32 && items_per_image < 12 && p.OH > 8) return C_TILE_S1_8;
