@@ -2,7 +2,8 @@
 // cores, split-bf16, weights in registers:
 //   stride 2: the fuse-down chains and the transition layers
 //             (models/seg_hrnet.py:176-220 fuse_layers[i][j], j < i; :343-377 transition layers);
-//   stride 1: the BasicBlock / Bottleneck 3x3 convs of the 64..128-channel branches (models/seg_hrnet.py:40-72).
+//   stride 1: the BasicBlock 3x3 convs of the 64-, 128- and 256-channel branches and of layer1.0
+//             (models/seg_hrnet.py:32-61).
 //
 // The generic tiling (conv_mfma.hip: one output row per wave, weights AND input through LDS) is LDS-bound:
 // 54 LDS reads per 54 MFMAs.  With 32-channel chunks the whole weight set of a 16-cout tile is
@@ -19,10 +20,12 @@
 // MFMAs leaves its SIMD's matrix pipe to ONE other wave (2 workgroups per CU):
 //   * global accesses go through buffer descriptors: an out-of-image pixel / row / column is a single
 //     select of an out-of-range offset (loads return 0 = the zero padding, stores are dropped), no
-//     exec-mask branches, 32-bit offsets, the image base in the scalar offset;
+//     exec-mask branches, 32-bit offsets, the image base in the scalar offset of the LOADS (the stores keep it in
+//     the vector offset: store-data hazard, see the epilogue);
 //   * the item decode divides by multiplication (host-computed reciprocals);
 //   * bias and weights of the next step are loaded a phase or more ahead of their use;
-//   * LDS operand reads run S2_RD rows ahead of the MFMAs that consume them.
+//   * LDS operand reads run one or two rows ahead of the MFMAs that consume them;
+//   * in the last chunk of an item the epilogue of each output row rides inside the last MFMA phase.
 #include "conv_cfg.h"
 #include "kernels.h"
 #include "sb.h"
