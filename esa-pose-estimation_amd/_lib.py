@@ -8,13 +8,14 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libesahrnet.so")
 MAX_BRANCHES = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Cfg(C.Structure):
     _fields_ = [("cin", C.c_int32), ("num_keypoints", C.c_int32), ("stem_width", C.c_int32),
                 ("widths", C.c_int32 * MAX_BRANCHES), ("blocks", (C.c_int32 * MAX_BRANCHES) * 4),
-                ("modules", C.c_int32 * 4), ("final_conv_kernel", C.c_int32), ("variant", C.c_int32)]
+                ("modules", C.c_int32 * 4), ("final_conv_kernel", C.c_int32), ("variant", C.c_int32),
+                ("precision", C.c_int32)]
 
 
 class AuxDesc(C.Structure):
@@ -43,6 +44,9 @@ _SIGS = {
     "esahrnet_abi_version": (C.c_int, []),
     "esahrnet_create": (C.c_int, [C.POINTER(Cfg), C.c_int, C.POINTER(C.c_void_p)]),
     "esahrnet_destroy": (C.c_int, [C.c_void_p]),
+    "esahrnet_handle_device": (C.c_int, [C.c_void_p]),
+    "esahrnet_debug_devstate": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "esahrnet_debug_set_launch_limit": (C.c_int, [C.c_longlong]),
     "esahrnet_conv_count": (C.c_int, [C.c_void_p]),
     "esahrnet_conv_desc_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ConvDesc)]),
     "esahrnet_set_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -54,6 +58,8 @@ _SIGS = {
     "esahrnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "esahrnet_keypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "esahrnet_keypoints_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "esahrnet_crops": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                  C.c_void_p, C.c_void_p]),
     "esahrnet_pnp_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

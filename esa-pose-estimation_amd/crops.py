@@ -55,6 +55,8 @@ def crop_batch(frames: torch.Tensor, bboxes, scale: int = 256, mean: float = MEA
         raise TypeError("frames must be a uint8 CUDA tensor [N, H, W] (no CPU fallback)")
     frames = frames.contiguous()
     n, fh, fw = frames.shape
+    if len(bboxes) != n:
+        raise ValueError(f"{len(bboxes)} detector boxes for {n} frames (crop_kernel reads one box per frame)")
     boxes, rates = [], []
     for b in bboxes:
         box, size = val_box(b, fw, fh)

@@ -20,6 +20,7 @@
 //      its accumulators having been initialised with b2 + x long before;
 //   5. ReLU, split, store.
 #include "conv_cfg.h"
+#include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
 
@@ -275,20 +276,8 @@ __global__ __launch_bounds__(BTHREADS, 1) void bblock32_kernel(BlockParams p, in
 
 int launch_bblock32(const BlockParams& p, hipStream_t stream) {
     if ((long long)p.H * p.W * 128 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    static bool attr_set = false;
-    static int cus = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bblock32_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        if (e != hipSuccess) return (int)e;
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(bblock32_kernel), LDS_TOTAL)) return e_;
+    const int cus = device_cus();
     const int tiles_x = (p.W + BT - 1) / BT, tiles_y = (p.H + BT - 1) / BT;
     const long long nitems = (long long)p.N * tiles_x * tiles_y;
     if (nitems <= 0 || nitems > 0x7fffffffLL) return (int)hipErrorInvalidValue;

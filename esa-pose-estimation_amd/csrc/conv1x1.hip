@@ -9,6 +9,7 @@
 // LDS one 32-cout chunk at a time (A operand: rows = output channels), the next chunk's fragments in
 // flight while the current one is consumed.  D[cout][pixel] leaves 4 consecutive channels of a pixel
 // per lane: 16-byte SB chunk stores (sb.h).
+#include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
 
@@ -99,13 +100,7 @@ template <int NCH>
 int launch_conv1x1_n(const ConvParams& p, hipStream_t stream) {
     auto kern = conv1x1_kernel<NCH>;
     const int lds = 2 * 4 * NCH * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const int tiles_per_row = (p.W + 15) / 16;
     const long long ntiles = (long long)p.N * p.H * tiles_per_row;
     const long long nblk = (ntiles + 3) / 4;

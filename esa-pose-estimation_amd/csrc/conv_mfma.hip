@@ -34,6 +34,7 @@
 // fragments of a chunk go global -> LDS by DMA (global_load_lds, no registers) and stay resident
 // across items for single-chunk layers (Cin = 32).
 #include "conv_cfg.h"
+#include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
 
@@ -459,14 +460,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_ring_kernel(ConvParams 
 template <int S, int TH, int MT>
 int launch_ring(const ConvParams& p, hipStream_t stream) {
     using C = ConvCfg<3, S, TH, MT>;
-    static bool attr_set = false;
     auto kern = conv_mfma_ring_kernel<S, TH, MT>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), C::LDS_BYTES)) return e_;
     const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
     const int ctiles = p.Coutp / (16 * MT);
     const long long nitems = (long long)p.N * tiles_y * tiles_x * ctiles;
@@ -476,15 +471,7 @@ int launch_ring(const ConvParams& p, hipStream_t stream) {
 }
 
 int persistent_grid(long long nitems) {
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        }
-        slots = 2 * cus;                     // two workgroups per CU (80 KB LDS each)
-    }
+    const int slots = 2 * device_cus();       // two workgroups per CU (80 KB LDS each)
     return (int)(nitems < slots ? nitems : slots);
 }
 
@@ -494,14 +481,8 @@ int persistent_grid(long long nitems) {
 template <int KS, int S, int TH, int MT, bool PERSIST>
 int launch_tp(const ConvParams& p, hipStream_t stream) {
     using C = ConvCfg<KS, S, TH, MT>;
-    static bool attr_set = false;
     auto kern = conv_mfma_kernel<KS, S, TH, MT, PERSIST>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), C::LDS_BYTES)) return e_;
     const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
     const int ctiles = p.Coutp / (16 * MT);
     const long long nitems = (long long)p.N * tiles_y * tiles_x * ctiles;

@@ -27,8 +27,11 @@
 //   * LDS operand reads run one or two rows ahead of the MFMAs that consume them;
 //   * in the last chunk of an item the epilogue of each output row rides inside the last MFMA phase.
 #include "conv_cfg.h"
+#include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
+#include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #ifdef S2_TRACE
@@ -389,17 +392,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
 
 uint32_t magic_of(int d) { return (uint32_t)(0xffffffffull / (uint64_t)d); }
 
+// images one launch may cover: the kernels address whole tensors with 31-bit byte offsets (buffer descriptors, OOB
+// marker 2^31).  Larger batches are cut into several launches over image ranges HERE, so that the kernel serving a
+// layer — and with it every bit of a crop's result — never depends on the batch size.
+std::atomic<long long> g_launch_limit{0x7fffffffLL};      // bytes; lowered only by tests (esahrnet_debug_set_launch_limit)
+int images_per_launch(const ConvParams& p) {
+    long long per = (long long)p.H * p.W * p.Cinp * 4;
+    if (p.nheads > 1) {
+        for (int h = 0; h < p.nheads; ++h) per = std::max(per, (long long)p.OH * p.OW * (p.hb[h + 1] - p.hb[h]) * 4);
+    } else {
+        per = std::max(per, (long long)p.OH * p.OW * p.Coutp * 4);
+    }
+    return (int)std::min<long long>(p.N, g_launch_limit.load(std::memory_order_relaxed) / std::max(per, 1LL));
+}
+
 template <int S, int TH, int MW, bool MH = false>
 int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
     using S2C = ConvCfg<3, S, TH, 2>;
-    auto kern = conv_s2c32_kernel<S, TH, MW, MH>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, S2C::XBYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    const int nmax = images_per_launch(p);
+    if (nmax < 1) return (int)hipErrorInvalidValue;
+    if (p.N > nmax) {
+        for (int n0 = 0; n0 < p.N; n0 += nmax) {
+            ConvParams q = p;
+            q.N = std::min(nmax, p.N - n0);
+            q.x = p.x + (size_t)n0 * p.H * p.W * p.Cinp * 4;
+            if (p.y) q.y = p.y + (size_t)n0 * p.OH * p.OW * p.Coutp * 4;
+            if (p.res) q.res = p.res + (size_t)n0 * p.OH * p.OW * p.Coutp * 4;
+            for (int h = 0; h < p.nheads && h < 3; ++h)
+                if (p.yh[h]) q.yh[h] = p.yh[h] + (size_t)n0 * p.OH * p.OW * (p.hb[h + 1] - p.hb[h]) * 4;
+            if (const int e = launch_s2c32_t<S, TH, MW, MH>(q, stream)) return e;
+        }
+        return 0;
     }
+    auto kern = conv_s2c32_kernel<S, TH, MW, MH>;
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), S2C::XBYTES)) return e_;
     StreamGeo geo;
     geo.tiles_x = (p.OW + TW - 1) / TW;
     geo.tiles_y = (p.OH + TH - 1) / TH;
@@ -410,15 +436,7 @@ int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
     geo.m_ct = magic_of(geo.ctiles);
     geo.m_tx = magic_of(geo.tiles_x);
     geo.m_ty = magic_of(geo.tiles_y);
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        }
-        slots = 2 * cus;
-    }
+    const int slots = 2 * device_cus();
     int grid = (int)(nitems < slots ? nitems : slots);
     if (grid > geo.ctiles) grid -= grid % geo.ctiles;   // grid stride keeps the cout slice of a workgroup constant
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), S2C::XBYTES, stream, p, geo);
@@ -427,11 +445,17 @@ int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
 
 }  // namespace
 
-// whole tensors must be addressable with 31-bit byte offsets (buffer descriptors, OOB marker 2^31)
+// test hook: bytes one stream-kernel launch may address (default and maximum 2^31 - 1)
+void set_stream_launch_limit(long long bytes) {
+    g_launch_limit.store(bytes > 0 && bytes < 0x7fffffffLL ? bytes : 0x7fffffffLL, std::memory_order_relaxed);
+}
+
+// one IMAGE must be addressable with 31-bit byte offsets (buffer descriptors, OOB marker 2^31); a batch that is not
+// is cut into image ranges by the launcher (images_per_launch), so this predicate does not look at N
 bool conv_s2c32_supported(const ConvParams& p) {
     return (p.Cinp & 31) == 0 && p.Cinp >= 32 && (p.Coutp & 31) == 0 && !p.out_f32 &&
-           (long long)p.N * p.H * p.W * p.Cinp * 4 < 0x7fffffffLL &&
-           (long long)p.N * p.OH * p.OW * p.Coutp * 4 < 0x7fffffffLL;
+           (long long)p.H * p.W * p.Cinp * 4 < 0x7fffffffLL &&
+           (long long)p.OH * p.OW * p.Coutp * 4 < 0x7fffffffLL;
 }
 
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream) {
@@ -441,10 +465,10 @@ int launch_conv_s2c32(const ConvParams& p, hipStream_t stream) {
 
 bool conv_s2c32_multi_supported(const ConvParams& p) {
     if (p.nheads < 2 || p.nheads > 3 || p.res || p.out_f32 || p.hb[0] != 0 || p.hb[p.nheads] != p.Coutp) return false;
-    if ((p.Cinp & 31) || p.Cinp < 32 || (long long)p.N * p.H * p.W * p.Cinp * 4 >= 0x7fffffffLL) return false;
+    if ((p.Cinp & 31) || p.Cinp < 32 || (long long)p.H * p.W * p.Cinp * 4 >= 0x7fffffffLL) return false;
     for (int h = 0; h < p.nheads; ++h) {
         const int c = p.hb[h + 1] - p.hb[h];
-        if (c <= 0 || (c & 31) || !p.yh[h] || (long long)p.N * p.OH * p.OW * c * 4 >= 0x7fffffffLL) return false;
+        if (c <= 0 || (c & 31) || !p.yh[h] || (long long)p.OH * p.OW * c * 4 >= 0x7fffffffLL) return false;
     }
     return true;
 }

@@ -43,7 +43,12 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* frames, 
     coef(dx, cols, S, sx0, sx1, ax0, ax1);
     coef(dy, rows, S, sy0, sy1, by0, by1);
     const unsigned char* f = frames + (size_t)n * FH * FW;
-    auto px = [&](int r, int c) { return (int)f[(size_t)(y0 + min(r, ys - 1)) * FW + x0 + min(c, xs - 1)]; };
+    // the box comes from the host (crops.val_box keeps it inside the frame); a C-ABI caller's bad box must not
+    // become an out-of-bounds read, so the source row / column are clamped to the frame as well
+    auto px = [&](int r, int c) {
+        const int yy = min(max(y0 + min(r, ys - 1), 0), FH - 1), xx = min(max(x0 + min(c, xs - 1), 0), FW - 1);
+        return (int)f[(size_t)yy * FW + xx];
+    };
     const int r0 = px(sy0, sx0) * ax0 + px(sy0, sx1) * ax1;
     const int r1 = px(sy1, sx0) * ax0 + px(sy1, sx1) * ax1;
     int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;

@@ -8,6 +8,7 @@
 // tensor, raw input straight from the caller's NCHW crop) and runs the (K+cin)*9*K MACs per
 // pixel on the f32 VALU with wave-uniform (scalar) weights.  K*(K+cin)*9 = 1188 MACs per pixel
 // for the 11-keypoint variant: 0.5 % of the network, HBM-write-bound (K*4 B per pixel out).
+#include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
 
@@ -122,13 +123,7 @@ int launch_final_t(const FinalParams& p, hipStream_t stream) {
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const size_t lds = (size_t)(p.K + p.cin) * FIH * FROW * sizeof(float);
     auto kern = final_kernel<KT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), 64 * 1024)) return e_;
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, p, tiles_x, tiles_y);
     return (int)hipGetLastError();
@@ -272,13 +267,7 @@ int launch_final_mfma_t(const FinalParams& p, hipStream_t stream) {
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const int lds = 2 * CG * MPLANE + M * NCH * 2048;
     auto kern = final_mfma_kernel<CG, M>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, p, p.wpk, tiles_x, tiles_y);
     return (int)hipGetLastError();
 }

@@ -23,6 +23,7 @@
 // h0 never leaves the register file.  Staging of chunk c+1 (global -> registers) is issued
 // before the math of chunk c and written to the other LDS buffer after it.
 // Epilogue: bias3 + ReLU + split -> SB store of h3.
+#include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
 
@@ -241,14 +242,8 @@ __global__ __launch_bounds__(HTHREADS, 1) void head_fused_kernel(HeadParams p, i
 template <int NCH0, int M3>
 int launch_head_t(const HeadParams& p, hipStream_t stream) {
     auto kern = head_fused_kernel<NCH0, M3>;
-    static bool attr_set = false;
     const int lds = 2 * (BUF_BYTES + (2 * NCH0 * 2 + M3 * 2) * 1024);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const int tiles_x = (p.W + HT - 1) / HT, tiles_y = (p.H + HT - 1) / HT;
     const long long nblk = (long long)p.N * tiles_x * tiles_y;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;

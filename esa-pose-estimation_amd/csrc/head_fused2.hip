@@ -23,6 +23,7 @@
 // B operand of W3 (permuted K order, as in head_fused.hip).  One barrier per 32-channel chunk; the
 // chunk c+1 data (t_1 tile, t_2/t_3 windows, W0/W3/bias) and the W_1 fragments of chunk c+2 are
 // produced while chunk c is consumed.
+#include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
 
@@ -376,15 +377,9 @@ __global__ __launch_bounds__(NW * 64, (NCH0 > 1 || NCH1 > 2) ? 2 : 4) void head_
 template <int NW, int NCH0, int NCH1, int M3, bool ULO>
 int launch_head2_t(const Head2Params& p, hipStream_t stream) {
     auto kern = head_fused2_kernel<NW, NCH0, NCH1, M3, ULO>;
-    static bool attr_set = false;
     const int lds = 2 * (rows1(NW) * 2 + rows2(NW) + rows3(NW)) * 1024 + 2 * ((4 * NCH0 + 2 * M3) * 1024 + 256) +
                     2 * 4 * NCH1 * 1024;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const int tiles_x = (p.W + HTW - 1) / HTW, tiles_y = (p.H + NW - 1) / NW;
     const long long nblk = (long long)p.N * tiles_x * tiles_y;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;

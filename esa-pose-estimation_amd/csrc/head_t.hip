@@ -14,6 +14,7 @@
 // stay in registers (A operand: rows = pixels), the weight fragments stream through LDS in 32-channel
 // chunks (B operand: columns = output channels), so D[pixel][cout] puts 4 consecutive pixels of one
 // channel in one lane -> 8-byte stores of hi / lo along the row.
+#include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
 
@@ -104,13 +105,7 @@ template <int NCH>
 int launch_head_t_n(const HeadTParams& p, hipStream_t stream) {
     auto kern = head_t_kernel<NCH>;
     const int lds = 2 * 4 * NCH * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const int tiles_per_row = p.XP / 16;
     const long long ntiles = (long long)p.N * p.h * tiles_per_row;
     const long long nblk = (ntiles + 3) / 4;

@@ -5,6 +5,9 @@
 
 namespace esa {
 
+// thread-local error text behind esahrnet_last_error() (plan.hip); returns 1 so that `return set_error(...)` reads well
+int set_error(const char* fmt, ...);
+
 // ---- implicit-GEMM convolution on MFMA (conv_mfma.hip) -------------------------------------
 struct ConvParams {
     const char* x;      // SB input  [N][H][W][Cinp]
@@ -36,6 +39,7 @@ const char* conv_kernel_name(const ConvParams& p, int k, int stride);
 bool conv_s2c32_supported(const ConvParams& p);
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream);
 int launch_conv_s1w(const ConvParams& p, hipStream_t stream);
+void set_stream_launch_limit(long long bytes);     // test hook, see conv_s2c32.hip images_per_launch
 // 1x1, Cinp in {64..384}: all input channels of 16 pixels in registers, weights streamed through LDS (conv1x1.hip)
 bool conv1x1_supported(const ConvParams& p);
 int launch_conv1x1(const ConvParams& p, hipStream_t stream);
@@ -179,7 +183,8 @@ int launch_resample_slice(const ResampleParams& p, hipStream_t s);
 int launch_zero_slice(char* y, long long npix, int y_pix_bytes, int c0, int nchan, hipStream_t s);
 
 // ---- arg-max + log-quadratic refine (keypoints.hip) ----------------------------------------
-int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, hipStream_t stream);
+// idx_out: optional int32 [planes], the flat index (row * W + column) of the arg-max
+int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, int* idx_out, hipStream_t stream);
 
 // ---- crop + edge-pad + 8-bit bilinear resize + normalise: u8 frames -> f32 [N][1][S][S] (crops.hip) ----
 int launch_crops(const unsigned char* frames, const int* boxes, float* out, int N, int FH, int FW, int S,

@@ -7,20 +7,23 @@
 // DPP/shuffle reduction and one LDS step across the waves pick the first row-major maximum
 // (== np.argmax / two-stage torch.max tie-break), then one lane evaluates the 9-tap
 // log-quadratic offset in f64 exactly as the reference's Python floats do.
-// NaN policy: comparisons with NaN are false, i.e. NaNs are skipped (the reference would
-// propagate them; a NaN heatmap is a broken model either way).
+// NaN policy = the reference's: np.argmax / torch.max treat NaN as the maximum and return the
+// FIRST NaN's index, the reported peak is NaN, and the refinement falls through (np.maximum(hm, 1e-10) and
+// math.log propagate the NaN, `offset < 1` is then false): integer coordinates of the first NaN, peak NaN.
 #include "kernels.h"
 
 namespace esa {
 namespace {
 
+// (v, i) beats (bv, bi) if it is larger, NaN counting as larger than every number, or equal with a lower index
 __device__ __forceinline__ void take(float v, int i, float& bv, int& bi) {
-    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    const bool vn = v != v, bn = bv != bv;
+    if (v > bv || (vn && !bn) || ((v == bv || (vn && bn)) && i < bi)) { bv = v; bi = i; }
 }
 
 constexpr int KT = 1024;        // 16 waves per plane: the sweep is latency-bound, it wants loads in flight
 
-__global__ __launch_bounds__(KT) void keypoints_kernel(const float* heat, int H, int W, float* kp) {
+__global__ __launch_bounds__(KT) void keypoints_kernel(const float* heat, int H, int W, float* kp, int* idx_out) {
     __shared__ float sv[KT / 64];
     __shared__ int si[KT / 64];
     const float* pl = heat + (size_t)blockIdx.x * H * W;
@@ -55,7 +58,11 @@ __global__ __launch_bounds__(KT) void keypoints_kernel(const float* heat, int H,
         const int px = bi % W, py = bi / W;
         float fx = (float)px, fy = (float)py;
         if (1 < px && px < W - 2 && 1 < py && py < H - 2) {   // inference.py:81
-            auto lg = [&](int yy, int xx) { return log((double)fmaxf(pl[yy * W + xx], 1e-10f)); };
+            // np.maximum(hm, 1e-10) of inference.py:141 (NaN-propagating, unlike fmaxf), then math.log in f64
+            auto lg = [&](int yy, int xx) {
+                const float v = pl[yy * W + xx];
+                return log((double)(v < 1e-10f ? 1e-10f : v));
+            };
             const double c = lg(py, px);
             const double hx = 0.5 * (lg(py, px + 1) - lg(py, px - 1));
             const double hy = 0.5 * (lg(py + 1, px) - lg(py - 1, px));
@@ -72,14 +79,15 @@ __global__ __launch_bounds__(KT) void keypoints_kernel(const float* heat, int H,
         kp[blockIdx.x * 3 + 0] = fx;
         kp[blockIdx.x * 3 + 1] = fy;
         kp[blockIdx.x * 3 + 2] = pl[bi];
+        if (idx_out) idx_out[blockIdx.x] = bi;
     }
 }
 
 }  // namespace
 
-int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, hipStream_t stream) {
+int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, int* idx_out, hipStream_t stream) {
     if (planes <= 0 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(keypoints_kernel, dim3((unsigned)planes), dim3(KT), 0, stream, heat, H, W, kp);
+    hipLaunchKernelGGL(keypoints_kernel, dim3((unsigned)planes), dim3(KT), 0, stream, heat, H, W, kp, idx_out);
     return (int)hipGetLastError();
 }
 

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/esahrnet.h"
+#include "devstate.h"
 #include "kernels.h"
 
 namespace esa {
@@ -130,6 +131,14 @@ struct ShapePlan {
 };
 
 }  // namespace
+
+int esa::set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return 1;
+}
 
 struct esahrnet_ctx {
     esahrnet_cfg cfg;
@@ -805,6 +814,8 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     if (cfg->num_keypoints < 1 || esa::final_kt(cfg->num_keypoints) < 0) return fail("num_keypoints=%d unsupported (1..32)", cfg->num_keypoints);
     if (cfg->stem_width < 1 || cfg->blocks[0][0] < 1) return fail("bad stem_width/blocks");
     if (cfg->variant != 0 && cfg->variant != 1) return fail("variant=%d unsupported (0: seg_hrnet/2, 1: seg_hrnet3)", cfg->variant);
+    if (cfg->precision != 0 && cfg->precision != 1) return fail("precision=%d unsupported (0: split-bf16, 1: bf16)", cfg->precision);
+    if (cfg->precision == 1 && cfg->variant != 0) return fail("precision 1 (bf16) is built for variant 0 only");
     if (cfg->variant == 1) {
         if (cfg->stem_width % 16) return fail("variant 1: stem_width must be a multiple of 16 (ChannelAttention ratio)");
         for (int b = 0; b < ESAHRNET_MAX_BRANCHES; ++b)
@@ -831,6 +842,18 @@ int esahrnet_destroy(esahrnet_handle h) {
     if (h->committed) { (void)hipSetDevice(h->device); }
     free_weights(*h);
     delete h;
+    return 0;
+}
+
+int esahrnet_handle_device(esahrnet_handle h) { return h ? h->device : -1; }
+
+int esahrnet_debug_devstate(int* kernel_device_entries, int* devices) {
+    esa::dev_state_counts(kernel_device_entries, devices);
+    return 0;
+}
+
+int esahrnet_debug_set_launch_limit(long long bytes) {
+    esa::set_stream_launch_limit(bytes);
     return 0;
 }
 
@@ -1459,13 +1482,19 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
     return 0;
 }
 
-int esahrnet_keypoints(const void* heat_dev, int n, int k, int height, int width, void* kp_dev,
-                       esahrnet_stream stream) {
+int esahrnet_keypoints_ex(const void* heat_dev, int n, int k, int height, int width, void* kp_dev, void* idx_dev,
+                          esahrnet_stream stream) {
     if (!heat_dev || !kp_dev || n <= 0 || k <= 0) return fail("keypoints: bad argument");
     const int rc = esa::launch_keypoints(static_cast<const float*>(heat_dev), n * k, height, width,
-                                         static_cast<float*>(kp_dev), static_cast<hipStream_t>(stream));
+                                         static_cast<float*>(kp_dev), static_cast<int*>(idx_dev),
+                                         static_cast<hipStream_t>(stream));
     if (rc) return fail("keypoints: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return 0;
+}
+
+int esahrnet_keypoints(const void* heat_dev, int n, int k, int height, int width, void* kp_dev,
+                       esahrnet_stream stream) {
+    return esahrnet_keypoints_ex(heat_dev, n, k, height, width, kp_dev, nullptr, stream);
 }
 
 int esahrnet_crops(const void* frames_dev, int n, int frame_h, int frame_w, const void* boxes_dev, int scale,

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/esahrnet.h"
+#include "kernels.h"
 
 namespace {
 
@@ -593,7 +594,9 @@ void pose_one(const float* kp, int k, const double* kp3d, const Cam& K, double x
 extern "C" int esahrnet_pnp_batch(const float* kp, int n, int k, const double* kp3d, const double* K9, const int* boxes_xy,
                                   const double* rates, double thresh, int min_k, int threads, double* q_out,
                                   double* t_out) {
-    if (!kp || !kp3d || !K9 || !boxes_xy || !rates || !q_out || !t_out || n < 0 || k < 1 || k > 64) return 1;
+    if (!kp || !kp3d || !K9 || !boxes_xy || !rates || !q_out || !t_out) return esa::set_error("pnp_batch: null argument");
+    if (n < 0) return esa::set_error("pnp_batch: negative image count %d", n);
+    if (k < 1 || k > 64) return esa::set_error("pnp_batch: %d keypoints per image unsupported (1..64)", k);
     const Cam K{K9[0], K9[4], K9[2], K9[5]};
     auto work = [&](int lo, int hi) {
         for (int i = lo; i < hi; ++i)

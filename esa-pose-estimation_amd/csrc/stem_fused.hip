@@ -14,6 +14,7 @@
 // conv1 pixels outside the image are forced to 0 (they are conv2's zero padding, not conv1
 // evaluated on padding).
 #include "conv_cfg.h"
+#include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
 
@@ -348,13 +349,7 @@ template <int CIN>
 int launch_sf64(const StemFusedParams& p, hipStream_t stream) {
     auto kern = stem_fused64_kernel<CIN>;
     const int lds = SC::XBYTES + CIN * RH * RPITCH * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + SF_TH - 1) / SF_TH;
     const long long nblk = (long long)p.N * tiles_x * tiles_y;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -366,13 +361,7 @@ template <int CIN, int CT>
 int launch_sf2(const StemFusedParams& p, hipStream_t stream) {
     auto kern = stem_fused_kernel<CIN, CT>;
     const int lds = SC::XBYTES + SC::WBYTES + CIN * RH * RPITCH * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + SF_TH - 1) / SF_TH;
     const int ctiles = p.Coutp / (16 * SF_MT * CT);
     const long long nblk = (long long)p.N * tiles_x * tiles_y * ctiles;

@@ -19,6 +19,7 @@ from __future__ import annotations
 import ctypes as C
 import logging
 import os
+import threading
 
 import numpy as np
 import torch
@@ -31,11 +32,17 @@ logger = logging.getLogger(__name__)
 BN_MOMENTUM = 0.01           # models/seg_hrnet.py:23 (irrelevant at inference, kept for parity)
 
 
-def _cfg_struct(config, cin: int, num_keypoints: int, variant: int = 0) -> _lib.Cfg:
+PRECISIONS = {"bf16x3": 0, "split-bf16": 0, "fp32": 0, "bf16": 1, 0: 0, 1: 1}
+
+
+def _cfg_struct(config, cin: int, num_keypoints: int, variant: int = 0, precision=0) -> _lib.Cfg:
     extra = config.MODEL.EXTRA.HIGH_RESOLUTION_NET if hasattr(config, "MODEL") else \
         config["MODEL"]["EXTRA"]["HIGH_RESOLUTION_NET"]
     s = _lib.Cfg()
     s.cin, s.num_keypoints, s.stem_width, s.variant = cin, num_keypoints, 64, variant
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision={precision!r}: expected one of {sorted(map(str, PRECISIONS))}")
+    s.precision = PRECISIONS[precision]
     fk = extra["FINAL_CONV_KERNEL"] if "FINAL_CONV_KERNEL" in extra else 1
     s.final_conv_kernel = int(fk)
     for i in range(4):
@@ -89,7 +96,10 @@ class HighResolutionNet(nn.Module):
         cin = int(kwargs.pop("cin", self.CIN))
         k = int(kwargs.pop("num_keypoints", self.NUM_KEYPOINTS))
         self._cin, self._k = cin, k
-        self._cfg_struct = _cfg_struct(config, cin, k, int(kwargs.pop("variant", self.VARIANT)))
+        # precision: "bf16x3" (default; fp32-grade split-bf16, BASELINE configs[1]) or "bf16" (single-pass bf16
+        # storage / fp32 accumulate, BASELINE configs[3]) — include/esahrnet.h esahrnet_cfg.precision
+        self._cfg_struct = _cfg_struct(config, cin, k, int(kwargs.pop("variant", self.VARIANT)),
+                                       kwargs.pop("precision", 0))
         object.__setattr__(self, "_rt", _Runtime(self._cfg_struct))
         self._descs = self._rt.conv_descs()
         for d in self._descs:
@@ -151,20 +161,73 @@ class HighResolutionNet(nn.Module):
         """Debug: run a forward keeping every intermediate; returns {name: f32 NCHW tensor}."""
         return self._rt.taps(self, x0)
 
+    # ---- weight-version tracking (an eager forward must not walk the module tree: val.py:112 calls the
+    # net once per image) ---------------------------------------------------------------------------
+    def _weight_tensors(self):
+        """Flat list of every parameter and buffer, rebuilt only after the module was converted
+        (`_apply`: .cuda()/.to()/.float()) or re-loaded."""
+        ts = self.__dict__.get("_wt_cache")
+        if ts is None:
+            ts = [t for t in self.state_dict(keep_vars=True).values()]
+            self.__dict__["_wt_cache"] = ts
+            step = max(1, len(ts) // 8)
+            self.__dict__["_wt_sentinels"] = ts[::step] + ts[-1:]
+        return ts
+
+    def _weights_key(self):
+        """What the folded/packed weights on a device are valid for.  load_state_dict, init_weights and
+        every conversion (.cuda()/.to()/.float()) bump the epoch through the hooks below; in-place edits
+        under no_grad are noticed through the autograd version counters of nine sentinel tensors spread
+        over the state_dict (any loop over the parameters touches them) — walking all 539 counters costs
+        40 us per forward, the reference calls the net once per image (val.py:112).  After editing single
+        tensors by hand (or through `.data`, which no version counter sees) call invalidate_weights()."""
+        self._weight_tensors()
+        return (self.__dict__.get("_wt_epoch", 0), *[t._version for t in self.__dict__["_wt_sentinels"]])
+
+    def invalidate_weights(self):
+        """Force a re-fold on the next forward (see _weights_key)."""
+        self.__dict__["_wt_cache"] = None
+        self.__dict__["_wt_epoch"] = self.__dict__.get("_wt_epoch", 0) + 1
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self.invalidate_weights()
+        return r
+
+    def load_state_dict(self, *a, **kw):
+        r = super().load_state_dict(*a, **kw)
+        self.invalidate_weights()
+        return r
+
+    def release_workspaces(self):
+        """Drop the cached scratch tensors of eager forwards (HIP graphs own theirs, see _Runtime)."""
+        self._rt.release_workspaces()
+
     def _replicate_for_data_parallel(self):
+        # nn.DataParallel (val.py:382, main.py:254): a replica has no Parameters of its own (torch re-attaches
+        # broadcast copies as plain attributes), so it keeps a reference to the module it was made from and
+        # the shared runtime folds THAT module's weights once per device.
         r = super()._replicate_for_data_parallel()
         object.__setattr__(r, "_rt", self._rt)
+        r.__dict__["_master"] = self.__dict__.get("_master", self)
         return r
 
 
 class _Runtime:
-    """One libesahrnet handle per device + caller-owned workspace tensors."""
+    """One libesahrnet handle per device + caller-owned workspace tensors.
+
+    Shared by a module and its DataParallel replicas (one Python thread per device): everything that
+    mutates the tables below happens under `self.lock`; the launches themselves run outside it, one
+    handle per device, so replicas do not serialise each other."""
+
+    WS_SHAPES_PER_DEVICE = 4     # eager scratch tensors kept per device (LRU)
 
     def __init__(self, cfg_struct):
         self.cfg = cfg_struct
         self.lib = _lib.lib()
+        self.lock = threading.RLock()
         self.handles = {}        # device index -> (handle, weight-version key)
-        self.ws = {}             # (device, n, h, w, keep) -> uint8 tensor
+        self.ws = {}             # (device, n, h, w, keep) -> uint8 tensor, insertion order = LRU order
         self._probe = self._create(-1)
 
     def _create(self, device):
@@ -205,28 +268,28 @@ class _Runtime:
     def launch_count(self):
         return self.lib.esahrnet_launch_count(self._probe)
 
-    @staticmethod
-    def _version_key(module):
-        return tuple(t._version for t in module.state_dict(keep_vars=True).values()) + \
-            tuple(id(t) for t in module.parameters())
-
     def _handle_for(self, module, device):
-        key = self._version_key(module)
+        master = module.__dict__.get("_master", module)     # a DataParallel replica folds its master's weights
+        key = master._weights_key()
         ent = self.handles.get(device.index)
         if ent is not None and ent[1] == key:
             return ent[0]
-        h = ent[0] if ent is not None else self._create(device.index)
-        sd = module.state_dict()
-        for i, d in enumerate(module._descs):
-            w, b = fold_conv(sd, d["name"], d["bn"], d["has_bias"])
-            _lib.check(self.lib.esahrnet_set_conv(h, i, w.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
-        for i, a in enumerate(module._aux):
-            w = np.ascontiguousarray(sd[a["name"]].detach().cpu().float().numpy())
-            _lib.check(self.lib.esahrnet_set_aux(h, i, w.ctypes.data_as(C.c_void_p)))
-        with torch.cuda.device(device):
-            _lib.check(self.lib.esahrnet_commit(h))
-        self.handles[device.index] = (h, key)
-        return h
+        with self.lock:
+            ent = self.handles.get(device.index)
+            if ent is not None and ent[1] == key:
+                return ent[0]
+            h = ent[0] if ent is not None else self._create(device.index)
+            sd = master.state_dict()
+            for i, d in enumerate(master._descs):
+                w, b = fold_conv(sd, d["name"], d["bn"], d["has_bias"])
+                _lib.check(self.lib.esahrnet_set_conv(h, i, w.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+            for i, a in enumerate(master._aux):
+                w = np.ascontiguousarray(sd[a["name"]].detach().cpu().float().numpy())
+                _lib.check(self.lib.esahrnet_set_aux(h, i, w.ctypes.data_as(C.c_void_p)))
+            with torch.cuda.device(device):
+                _lib.check(self.lib.esahrnet_commit(h))
+            self.handles[device.index] = (h, key)
+            return h
 
     def _check_input(self, module, x0):
         if not isinstance(x0, torch.Tensor) or x0.dim() != 4:
@@ -238,20 +301,36 @@ class _Runtime:
             raise TypeError(f"expected float32 crops, got {x0.dtype}")
         if x0.shape[1] != module._cin:
             raise ValueError(f"expected {module._cin} input channels, got {x0.shape[1]}")
-        p = next(module.parameters())
-        if p.device != x0.device:
-            raise RuntimeError(f"input on {x0.device} but parameters on {p.device}")
+        if "_master" not in module.__dict__:     # (a replica runs wherever DataParallel scattered its input)
+            p = module._weight_tensors()[0]
+            if p.device != x0.device:
+                raise RuntimeError(f"input on {x0.device} but parameters on {p.device}")
         return x0.contiguous()
 
+    def release_workspaces(self):
+        with self.lock:
+            self.ws.clear()
+
     def _workspace(self, h, device, n, hh, ww, keep):
+        """Scratch for one forward.  Contract: while the stream is being CAPTURED into a HIP
+        graph the scratch is a fresh tensor allocated inside the capture (the graph's private pool owns it, like
+        any temporary of a captured torch op) and is never cached, so no graph ever holds a pointer into the
+        eager cache; eager forwards share a small per-device LRU of scratch tensors, protected by
+        record_stream."""
         nbytes = C.c_size_t()
         _lib.check(self.lib.esahrnet_workspace_bytes(h, n, hh, ww, C.byref(nbytes)))
-        key = (device.index, n, hh, ww, keep)
-        ws = self.ws.get(key)
-        if ws is None or ws.numel() < nbytes.value:
-            self.ws = {k: v for k, v in self.ws.items() if k[0] != device.index}   # one shape cached per device
+        if torch.cuda.is_current_stream_capturing():
             ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=device)
-            self.ws[key] = ws
+        else:
+            key = (device.index, n, hh, ww, keep)
+            with self.lock:
+                ws = self.ws.pop(key, None)
+                if ws is None or ws.numel() < nbytes.value + 256:
+                    ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=device)
+                self.ws[key] = ws                                    # most recently used last
+                mine = [k for k in self.ws if k[0] == device.index]
+                for k in mine[: max(0, len(mine) - self.WS_SHAPES_PER_DEVICE)]:
+                    del self.ws[k]
         off = (-ws.data_ptr()) % 256
         return ws, ws.data_ptr() + off, nbytes.value
 
@@ -263,12 +342,16 @@ class _Runtime:
         _lib.check(self.lib.esahrnet_set_debug_keep(h, 1 if keep else 0))
         ws, ws_ptr, ws_bytes = self._workspace(h, dev, n, hh, ww, keep)
         heat = torch.empty((n, module._k, hh, ww), dtype=torch.float32, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
-            _lib.check(self.lib.esahrnet_forward(h, x.data_ptr(), n, hh, ww, heat.data_ptr(), ws_ptr,
-                                                 ws_bytes, C.c_void_p(stream)))
-        ws.record_stream(torch.cuda.current_stream(dev))
-        x.record_stream(torch.cuda.current_stream(dev))
+        ts = torch.cuda.current_stream(dev)
+        args = (h, x.data_ptr(), n, hh, ww, heat.data_ptr(), ws_ptr, ws_bytes, C.c_void_p(ts.cuda_stream))
+        if torch.cuda.current_device() == dev.index:
+            rc = self.lib.esahrnet_forward(*args)
+        else:
+            with torch.cuda.device(dev):
+                rc = self.lib.esahrnet_forward(*args)
+        _lib.check(rc)
+        ws.record_stream(ts)
+        x.record_stream(ts)
         return heat
 
     def forward_timed(self, module, x0):

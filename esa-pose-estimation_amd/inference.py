@@ -21,9 +21,7 @@ import torch
 from . import _lib
 
 
-def heatmaps_to_keypoints(heat: torch.Tensor) -> torch.Tensor:
-    """f32 cuda [N,K,H,W] -> f32 cuda [N,K,3] = (x, y, peak); x=col, y=row, 0-based,
-    sub-pixel refined exactly as inference.my_taylor does; peak is the raw maximum."""
+def _keypoints(heat: torch.Tensor, want_index: bool):
     if not isinstance(heat, torch.Tensor) or heat.dim() != 4:
         raise ValueError("expected a 4-D tensor [N, K, H, W]")
     if not heat.is_cuda:
@@ -33,10 +31,18 @@ def heatmaps_to_keypoints(heat: torch.Tensor) -> torch.Tensor:
     heat = heat.contiguous()
     n, k, h, w = heat.shape
     kp = torch.empty((n, k, 3), dtype=torch.float32, device=heat.device)
+    idx = torch.empty((n, k), dtype=torch.int32, device=heat.device) if want_index else None
     stream = torch.cuda.current_stream(heat.device).cuda_stream
     with torch.cuda.device(heat.device):
-        _lib.check(_lib.lib().esahrnet_keypoints(heat.data_ptr(), n, k, h, w, kp.data_ptr(), C.c_void_p(stream)))
-    return kp
+        _lib.check(_lib.lib().esahrnet_keypoints_ex(heat.data_ptr(), n, k, h, w, kp.data_ptr(),
+                                                    idx.data_ptr() if want_index else None, C.c_void_p(stream)))
+    return kp, idx
+
+
+def heatmaps_to_keypoints(heat: torch.Tensor) -> torch.Tensor:
+    """f32 cuda [N,K,H,W] -> f32 cuda [N,K,3] = (x, y, peak); x=col, y=row, 0-based,
+    sub-pixel refined exactly as inference.my_taylor does; peak is the raw maximum."""
+    return _keypoints(heat, False)[0]
 
 
 def _to_device(hm):
@@ -49,19 +55,17 @@ def _to_device(hm):
 
 
 def get_max_preds(batch_heatmaps):
-    """inference.py:22-51 contract: -> (preds [N,K,2] f32 integer coordinates, maxvals [N,K,1])."""
+    """inference.py:22-51 contract: -> (preds [N,K,2] f32 integer coordinates, maxvals [N,K,1]).
+    Runs the same HIP kernel as heatmaps_to_keypoints (keypoints.hip), which also hands back the flat index of
+    its first-occurrence arg-max: preds = (idx % W, idx // W), maxvals = the raw peak."""
     assert isinstance(batch_heatmaps, (np.ndarray, torch.Tensor)), \
         'batch_heatmaps should be numpy.ndarray'
     t = _to_device(batch_heatmaps)
-    # integer arg-max = refined coordinate with the refinement undone is not recoverable, so the
-    # kernel is asked on a plane copy whose refinement cannot trigger: use the peak index directly.
-    n, k, h, w = t.shape
-    flat = t.reshape(n, k, -1)
-    # first-occurrence arg-max on the device (torch.max over a flattened plane has the same
-    # tie-break as np.argmax, SURVEY.md Appendix C)
-    maxvals, idx = torch.max(flat, dim=2)
-    preds = torch.stack([(idx % w).float(), torch.div(idx, w, rounding_mode="floor").float()], dim=2)
-    return preds.cpu().numpy(), maxvals.unsqueeze(-1).cpu().numpy()
+    kp, idx = _keypoints(t, True)
+    w = t.shape[3]
+    idx = idx.cpu().numpy()
+    preds = np.stack([(idx % w).astype(np.float32), (idx // w).astype(np.float32)], axis=2)
+    return preds, kp[..., 2:3].cpu().numpy()
 
 
 def get_final(hm, coords=None):

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define ESAHRNET_MAX_BRANCHES 4
-#define ESAHRNET_ABI_VERSION 2
+#define ESAHRNET_ABI_VERSION 3
 
 typedef struct esahrnet_ctx* esahrnet_handle;
 typedef void* esahrnet_stream; /* hipStream_t */
@@ -51,6 +51,12 @@ typedef struct esahrnet_cfg {
     int32_t variant;             /* 0: seg_hrnet.py / seg_hrnet2.py;  1: seg_hrnet3.py (CBAM in every
                                     BasicBlock and on the 64-ch pre-BN stem skip, 3x3 last_layer[0],
                                     output_layer over [heatmaps, skip]; models/seg_hrnet3.py)         */
+    int32_t precision;           /* arithmetic of the convolutions (not a reference knob: BASELINE.json configs):
+                                    0: split-bf16 hi/lo operands, 3 MFMAs per product, f32 accumulate — fp32-grade
+                                       (heatmap L_inf ~1e-5), the mode of configs[1] / configs[2];
+                                    1: bf16 activations and weights stored ONCE (half the bytes, one MFMA per
+                                       product), f32 accumulate, f32 folded-BN bias epilogue — configs[3]
+                                       (heatmap L_inf ~1e-2); variant 0 only                                   */
 } esahrnet_cfg;
 
 /* A parameter tensor that is not a convolution of the main graph (variant 1: the CBAM weights). */
@@ -75,6 +81,8 @@ int esahrnet_abi_version(void);
  * will live on; nothing touches the device until esahrnet_commit. */
 int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out);
 int esahrnet_destroy(esahrnet_handle h);
+/* Device ordinal the handle was created for. */
+int esahrnet_handle_device(esahrnet_handle h);
 
 int esahrnet_conv_count(esahrnet_handle h);
 int esahrnet_conv_desc_get(esahrnet_handle h, int index, esahrnet_conv_desc* out);
@@ -101,6 +109,11 @@ int esahrnet_forward(esahrnet_handle h, const void* x_dev, int n, int height, in
  * first-occurrence arg-max, log-quadratic sub-pixel refine, raw peak value. */
 int esahrnet_keypoints(const void* heat_dev, int n, int k, int height, int width,
                        void* kp_dev, esahrnet_stream stream);
+/* Same, and additionally idx_dev: int32 [n][k] = row * width + column of the arg-max (the integer coordinates
+ * inference.py:22-51 get_max_preds returns; NULL: not written).  A NaN in a plane is the maximum, as for
+ * np.argmax / torch.max: first NaN's index, peak NaN, no refinement. */
+int esahrnet_keypoints_ex(const void* heat_dev, int n, int k, int height, int width,
+                          void* kp_dev, void* idx_dev, esahrnet_stream stream);
 
 /* Loader stage in front of the path (data_load_val.py:139-187): for each of n 8-bit frames
  * [frame_h][frame_w] take the clamped box boxes[i] = (x0, y0, x1, y1) (int32, device), edge-pad it the
@@ -163,6 +176,14 @@ int esahrnet_op_conv(const void* x_dev, int n, int cin, int height, int width,
 int esahrnet_op_fuse(const void* const* xs_dev, const int* hs, const int* ws, int nterms,
                      int n, int c, int height, int width, int relu, void* y_dev,
                      esahrnet_stream stream);
+
+/* ---- test hooks ------------------------------------------------------------------------------------ */
+/* Launch state is kept per DEVICE (dynamic-LDS limits raised per kernel and device, CU counts), never in
+ * process-wide flags: number of (kernel, device) entries and of devices seen so far. */
+int esahrnet_debug_devstate(int* kernel_device_entries, int* devices);
+/* Bytes one launch of the stream convolution kernels may address (default and maximum 2^31 - 1); batches beyond it
+ * are cut into image ranges on the host.  Lowered by the tests to exercise the cut at small sizes; 0 restores. */
+int esahrnet_debug_set_launch_limit(long long bytes);
 
 #ifdef __cplusplus
 }

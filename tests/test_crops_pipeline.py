@@ -56,6 +56,15 @@ def test_gpu_crops_bit_exact_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_gpu_crop_batch_rejects_a_box_count_mismatch():
+    frames = torch.zeros((3, 1200, 1920), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError, match="boxes"):
+        crops.crop_batch(frames, BOXES[:2])
+    with pytest.raises(ValueError, match="boxes"):
+        crops.crop_batch(frames, BOXES[:4])
+
+
+@pytest.mark.gpu
 def test_gpu_pipeline_runs_frames_to_csv(tmp_path):
     """Plumbing of the whole loop with random weights (poses are meaningless, shapes and flow are not)."""
     from esa_pose_estimation_amd import config, seg_hrnet3

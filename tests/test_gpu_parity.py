@@ -455,3 +455,160 @@ def test_hrnet3_intermediates_match_oracle(env):
             err = (taps[name].cpu() - ref).abs().max().item()
             assert err <= GUARD, (name, err)
     assert (taps["heatmaps"].cpu() - out_ref).abs().max().item() <= GUARD
+
+
+# ------------------------------------------------------------------------------------- boundary (round 2)
+def test_dataparallel_wrapper_and_replicas(env):
+    """val.py:380-388: `net = DataParallel(NetWrapper(net)).cuda()`, weights loaded through `net.module.net`,
+    forward through the wrapper.  Plus the replica path DataParallel takes with more than one device
+    (torch.nn.parallel.replicate -> replicas without Parameters of their own), here with every replica on
+    device 0, from two threads at once as parallel_apply does."""
+    import threading
+
+    class NetWrapper(torch.nn.Module):          # shape of the reference's wrapper (val.py:70-80): net + loss glue
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, image):
+            return self.net(image)
+
+    net, sd = _build(env, "seg_hrnet2", (8, 16, 32, 64), 31)
+    x = env["synth"].make_crops(4, 1, 64, 64, seed=31).cuda()
+    with torch.no_grad():
+        want = net(x).clone()
+    wrapped = torch.nn.DataParallel(NetWrapper(net), device_ids=[0]).cuda()
+    wrapped.module.net.load_state_dict(sd)                   # load_model(net.module.net, ...) of val.py:387
+    torch.optim.SGD(wrapped.parameters(), lr=0.002, momentum=0.9)
+    wrapped.eval()
+    with torch.no_grad():
+        got = wrapped(x)
+    assert torch.equal(got, want)
+    reps = torch.nn.parallel.replicate(wrapped.module, [0, 0])
+    outs = [None, None]
+
+    def run(i):
+        with torch.no_grad():
+            outs[i] = reps[i](x[2 * i:2 * i + 2])
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(outs), want)
+    k, d = C.c_int(), C.c_int()
+    env["L"].check(env["lib"].esahrnet_debug_devstate(C.byref(k), C.byref(d)))
+    assert d.value == 1 and k.value >= 1                     # one device seen, attributes keyed per (kernel, device)
+
+
+def test_graph_replay_survives_eager_forwards_of_other_shapes(env):
+    """a captured graph must not hold a pointer into scratch that a later eager forward of another
+    shape releases.  Scratch of a captured forward is allocated inside the capture (graph-private pool)."""
+    net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 0)
+    x = env["synth"].make_crops(2, 1, 64, 64, seed=1).cuda()
+    with torch.no_grad():
+        want = net(x).clone()                         # eager first: the cached scratch exists before the capture
+        static_x = x.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            net(static_x)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = net(static_x)
+        # eager forwards of other batch sizes / shapes evict and recycle the eager scratch ...
+        junk = []
+        for n, hw in ((5, 64), (1, 96), (3, 32), (7, 64), (2, 128)):
+            junk.append(net(env["synth"].make_crops(n, 1, hw, hw, seed=n).cuda()))
+        junk.append(torch.full((64 << 20,), 7, dtype=torch.uint8, device="cuda"))     # ... and something reuses it
+        net.release_workspaces()
+        torch.cuda.synchronize()
+        static_x.copy_(x)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+        assert torch.equal(net(x), want)
+
+
+def test_stream_kernel_batch_cut_is_bit_identical(env):
+    """The stream kernels address a launch with 31-bit offsets; a batch beyond 2 GiB is cut into image ranges on
+    the host, so the kernel choice (and every bit of a crop's result) does not depend on the batch size.  The cut
+    is exercised here by lowering the limit to 3 images' worth."""
+    synth, lib, L = env["synth"], env["lib"], env["L"]
+    n, cin, cout, h, w = 8, 64, 64, 32, 32
+    x = torch.from_numpy(synth.normal("cx", 21, (n, cin, h, w))).cuda()
+    wt = synth.normal("cw", 22, (cout, cin, 3, 3), float(np.sqrt(1.0 / (cin * 9))))
+    b = synth.normal("cb", 23, (cout,), 0.1)
+    res = torch.from_numpy(synth.normal("cr", 24, (n, cout, h, w))).cuda()
+
+    def run(stride, use_res):
+        oh = h // stride
+        y = torch.full((n, cout, oh, oh), float("nan"), device="cuda")
+        L.check(lib.esahrnet_op_conv(x.data_ptr(), n, cin, h, w, wt.ctypes.data_as(C.c_void_p),
+                                     b.ctypes.data_as(C.c_void_p), cout, 3, stride, 1,
+                                     res.data_ptr() if use_res else None, y.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        return y
+    try:
+        for stride, use_res in ((1, True), (2, False)):
+            whole = run(stride, use_res)
+            L.check(lib.esahrnet_debug_set_launch_limit(3 * h * w * cin * 4 + 1))
+            cut = run(stride, use_res)
+            L.check(lib.esahrnet_debug_set_launch_limit(0))
+            assert torch.equal(whole, cut) and bool(torch.isfinite(cut).all())
+    finally:
+        L.check(lib.esahrnet_debug_set_launch_limit(0))
+
+
+def test_eager_forward_host_overhead(env):
+    """val.py:112 calls the net once per image: the Python side of one eager forward (checks, weight-version key,
+    scratch lookup, ctypes call with ~90 launches inside) is measured with the GPU idle-waiting excluded."""
+    import time
+    net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 0)
+    x = env["synth"].make_crops(1, 1, 256, 256, seed=1).cuda()
+    with torch.no_grad():
+        for _ in range(3):
+            net(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            net(x)
+        host = (time.perf_counter() - t0) / 20
+        torch.cuda.synchronize()
+    rt = net._rt
+    t0 = time.perf_counter()
+    for _ in range(200):
+        net._weights_key()
+    key = (time.perf_counter() - t0) / 200
+    print(f"eager forward: {host * 1e6:.0f} us of host time per call (of which weights key {key * 1e6:.1f} us)")
+    assert key < 50e-6
+
+
+def test_keypoints_nan_policy_is_the_references(env):
+    """np.argmax / torch.max treat NaN as the maximum (first NaN's index), the peak is NaN and
+    get_final's refinement falls through.  The oracle is numpy + math and inherits exactly that; planes: NaN in
+    the interior (refinable position), two NaNs (first wins), NaN next to the true peak, all-NaN, -inf plane."""
+    rng = np.random.RandomState(5)
+    hm = rng.rand(1, 6, 24, 32).astype(np.float32) * 0.5
+    hm[0, 0, 10, 12] = np.nan
+    hm[0, 1, 5, 7] = np.nan
+    hm[0, 1, 3, 30] = np.nan                       # earlier in row-major order
+    hm[0, 2, 8, 8] = 5.0
+    hm[0, 2, 8, 9] = np.nan
+    hm[0, 3] = np.nan
+    hm[0, 4] = -np.inf
+    hm[0, 5, 12, 16] = 3.0                         # a clean plane rides along
+    with np.errstate(all="ignore"):
+        ref = env["kref"].heatmaps_to_keypoints(hm)
+    kp = env["inference"].heatmaps_to_keypoints(torch.from_numpy(hm).cuda()).cpu().numpy()
+    assert np.array_equal(np.isnan(kp), np.isnan(ref))
+    assert np.array_equal(kp[..., :2][~np.isnan(ref[..., :2])], ref[..., :2][~np.isnan(ref[..., :2])]) or \
+        np.nanmax(np.abs(kp[..., :2] - ref[..., :2])) <= 2e-5
+    assert [tuple(kp[0, i, :2]) for i in range(5)] == [(12.0, 10.0), (30.0, 3.0), (9.0, 8.0), (0.0, 0.0), (0.0, 0.0)]
+    assert np.isnan(kp[0, :4, 2]).all() and kp[0, 4, 2] == -np.inf
+    preds, maxvals = env["inference"].get_max_preds(hm)
+    with np.errstate(all="ignore"):
+        rc, rm = env["kref"].argmax_keypoints(hm)
+    assert np.array_equal(preds, rc) and np.array_equal(np.isnan(maxvals[..., 0]), np.isnan(rm))

@@ -187,3 +187,109 @@ def test_packed_weight_layout_roundtrip():
     assert lib.esahrnet_set_conv(h, 1, w.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) != 0
     assert b"non-finite" in lib.esahrnet_last_error()
     assert lib.esahrnet_commit(h) != 0 and b"never set" in lib.esahrnet_last_error()
+
+
+# ---------------------------------------------------------------------------- one handle per device
+def _tiny_cfg(precision=0):
+    net = seg_hrnet2.get_seg_model(config.make_config(widths=(8, 16, 32, 64)), precision=precision)
+    return net, net._rt
+
+
+def test_two_handles_share_no_mutable_state():
+    """include/esahrnet.h: one handle per device, nothing shared between handles (the reference's wrapper is
+    single-process nn.DataParallel, val.py:382: one replica per GPU in one process).  Two handles for device
+    ordinals 0 and 1 are built here without a GPU: weights set on one are not 'set' on the other, each keeps its
+    own ordinal, its own debug flags and its own per-shape plan."""
+    net, rt = _tiny_cfg()
+    lib = rt.lib
+    h0, h1 = rt._create(0), rt._create(1)
+    try:
+        assert lib.esahrnet_handle_device(h0) == 0 and lib.esahrnet_handle_device(h1) == 1
+        sd = net.state_dict()
+        for i, d in enumerate(net._descs):
+            w, b = fold.fold_conv(sd, d["name"], d["bn"], d["has_bias"])
+            _lib.check(lib.esahrnet_set_conv(h0, i, w.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+        assert lib.esahrnet_commit(h1) != 0
+        assert "never set" in lib.esahrnet_last_error().decode()          # h1 saw none of h0's weights
+        assert lib.esahrnet_commit(h0) != 0
+        assert "no HIP device" in lib.esahrnet_last_error().decode()      # h0 is complete: fails only for the GPU
+        a, b = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.esahrnet_set_debug_keep(h0, 1))                    # keep-all planning on h0 only
+        _lib.check(lib.esahrnet_workspace_bytes(h0, 2, 64, 64, C.byref(a)))
+        _lib.check(lib.esahrnet_workspace_bytes(h1, 2, 64, 64, C.byref(b)))
+        assert a.value > b.value
+    finally:
+        lib.esahrnet_destroy(h0)
+        lib.esahrnet_destroy(h1)
+
+
+def test_launchers_keep_no_process_wide_state():
+    """The launchers used to cache `static bool attr_set` / `static int slots|cus`: set for whichever device
+    launched first, racy under DataParallel's thread per replica.  That state now lives in csrc/devstate.h, keyed
+    by (kernel, device) behind a mutex; no launcher may declare a mutable function-local or file-scope static."""
+    csrc = os.path.join(ROOT, "esa-pose-estimation_amd", "csrc")
+    bad = []
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")) or f == "devstate.h":
+            continue
+        for ln, line in enumerate(open(os.path.join(csrc, f)), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bstatic\s+(?!const\b|constexpr\b|inline\b|__device__|int\s+run_forward|const\s)(bool|int|unsigned|float|double|hip\w+|std::\w+)\s+\w+\s*(=|;)", code):
+                bad.append(f"{f}:{ln}: {line.strip()}")
+    assert not bad, bad
+    k, d = C.c_int(-1), C.c_int(-1)
+    _lib.check(_lib.lib().esahrnet_debug_devstate(C.byref(k), C.byref(d)))
+    assert k.value >= 0 and d.value >= 0
+
+
+def test_weights_key_and_replicas():
+    """An eager forward must not walk the module tree (val.py:112 calls the net once per image): the key the
+    packed weights are valid for costs a few us and still moves on load_state_dict / init_weights / .to() /
+    in-place edits of the parameters; a DataParallel replica (no Parameters of its own) folds its master's."""
+    import time
+    net, rt = _tiny_cfg()
+    k0 = net._weights_key()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        net._weights_key()
+    assert (time.perf_counter() - t0) / 200 < 50e-6
+    net.load_state_dict(net.state_dict())
+    k1 = net._weights_key()
+    assert k1 != k0
+    net.init_weights()
+    k2 = net._weights_key()
+    assert k2 != k1
+    net.float()
+    k3 = net._weights_key()
+    assert k3 != k2
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    assert net._weights_key() != k3
+    k4 = net._weights_key()
+    net.invalidate_weights()
+    assert net._weights_key() != k4
+    rep = net._replicate_for_data_parallel()
+    assert rep.__dict__["_master"] is net and rep._rt is net._rt
+    assert rep._replicate_for_data_parallel().__dict__["_master"] is net
+    with pytest.raises(ValueError):
+        seg_hrnet2.get_seg_model(config.make_config(), precision="fp8")
+
+
+def test_crop_batch_checks_box_count():
+    from esa_pose_estimation_amd import crops
+    with pytest.raises(TypeError):
+        crops.crop_batch(torch.zeros(2, 8, 8, dtype=torch.uint8), [(0, 0, 4, 4)])      # CPU tensor: no fallback
+    src = open(os.path.join(ROOT, "esa-pose-estimation_amd", "crops.py")).read()
+    assert "len(bboxes) != n" in src
+
+
+def test_pnp_batch_bad_argument_sets_error_text():
+    lib = _lib.lib()
+    kp = np.zeros((1, 65, 3), np.float32)
+    z = np.zeros(9)
+    rc = lib.esahrnet_pnp_batch(kp.ctypes.data_as(C.c_void_p), 1, 65, z.ctypes.data_as(C.c_void_p),
+                                z.ctypes.data_as(C.c_void_p), np.zeros(2, np.int32).ctypes.data_as(C.c_void_p),
+                                z.ctypes.data_as(C.c_void_p), 0.8, 24, 1, z.ctypes.data_as(C.c_void_p),
+                                z.ctypes.data_as(C.c_void_p))
+    assert rc != 0 and "65 keypoints" in lib.esahrnet_last_error().decode()
