@@ -227,7 +227,8 @@ class _Runtime:
         self.lib = _lib.lib()
         self.lock = threading.RLock()
         self.handles = {}        # device index -> (handle, weight-version key)
-        self.ws = {}             # (device, n, h, w, keep) -> uint8 tensor, insertion order = LRU order
+        self.dev_locks = {}      # device index -> lock serialising the enqueues of that device's handle
+        self.ws = {}             # (device, stream, n, h, w, keep) -> uint8 tensor, insertion order = LRU order
         self._probe = self._create(-1)
 
     def _create(self, device):
@@ -311,18 +312,18 @@ class _Runtime:
         with self.lock:
             self.ws.clear()
 
-    def _workspace(self, h, device, n, hh, ww, keep):
+    def _workspace(self, h, device, stream, n, hh, ww, keep):
         """Scratch for one forward.  Contract: while the stream is being CAPTURED into a HIP
         graph the scratch is a fresh tensor allocated inside the capture (the graph's private pool owns it, like
         any temporary of a captured torch op) and is never cached, so no graph ever holds a pointer into the
-        eager cache; eager forwards share a small per-device LRU of scratch tensors, protected by
-        record_stream."""
+        eager cache; eager forwards share a small per-device LRU of scratch tensors, keyed by stream and shape
+        (two streams never share scratch) and protected by record_stream."""
         nbytes = C.c_size_t()
         _lib.check(self.lib.esahrnet_workspace_bytes(h, n, hh, ww, C.byref(nbytes)))
         if torch.cuda.is_current_stream_capturing():
             ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=device)
         else:
-            key = (device.index, n, hh, ww, keep)
+            key = (device.index, stream.cuda_stream, n, hh, ww, keep)
             with self.lock:
                 ws = self.ws.pop(key, None)
                 if ws is None or ws.numel() < nbytes.value + 256:
@@ -334,22 +335,32 @@ class _Runtime:
         off = (-ws.data_ptr()) % 256
         return ws, ws.data_ptr() + off, nbytes.value
 
+    def _device_lock(self, index):
+        lk = self.dev_locks.get(index)
+        if lk is None:
+            with self.lock:
+                lk = self.dev_locks.setdefault(index, threading.RLock())
+        return lk
+
     def forward(self, module, x0, keep=False):
         x = self._check_input(module, x0)
         n, _, hh, ww = x.shape
         dev = x.device
-        h = self._handle_for(module, dev)
-        _lib.check(self.lib.esahrnet_set_debug_keep(h, 1 if keep else 0))
-        ws, ws_ptr, ws_bytes = self._workspace(h, dev, n, hh, ww, keep)
-        heat = torch.empty((n, module._k, hh, ww), dtype=torch.float32, device=dev)
         ts = torch.cuda.current_stream(dev)
-        args = (h, x.data_ptr(), n, hh, ww, heat.data_ptr(), ws_ptr, ws_bytes, C.c_void_p(ts.cuda_stream))
-        if torch.cuda.current_device() == dev.index:
-            rc = self.lib.esahrnet_forward(*args)
-        else:
-            with torch.cuda.device(dev):
+        # calls on one handle are not re-entrant (include/esahrnet.h): threads that share a device enqueue one
+        # after the other; threads on different devices (DataParallel's replicas) do not wait for each other
+        with self._device_lock(dev.index):
+            h = self._handle_for(module, dev)
+            _lib.check(self.lib.esahrnet_set_debug_keep(h, 1 if keep else 0))
+            ws, ws_ptr, ws_bytes = self._workspace(h, dev, ts, n, hh, ww, keep)
+            heat = torch.empty((n, module._k, hh, ww), dtype=torch.float32, device=dev)
+            args = (h, x.data_ptr(), n, hh, ww, heat.data_ptr(), ws_ptr, ws_bytes, C.c_void_p(ts.cuda_stream))
+            if torch.cuda.current_device() == dev.index:
                 rc = self.lib.esahrnet_forward(*args)
-        _lib.check(rc)
+            else:
+                with torch.cuda.device(dev):
+                    rc = self.lib.esahrnet_forward(*args)
+            _lib.check(rc)
         ws.record_stream(ts)
         x.record_stream(ts)
         return heat
@@ -360,7 +371,7 @@ class _Runtime:
         dev = x.device
         h = self._handle_for(module, dev)
         _lib.check(self.lib.esahrnet_set_debug_keep(h, 0))
-        ws, ws_ptr, ws_bytes = self._workspace(h, dev, n, hh, ww, False)
+        ws, ws_ptr, ws_bytes = self._workspace(h, dev, torch.cuda.current_stream(dev), n, hh, ww, False)
         heat = torch.empty((n, module._k, hh, ww), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         nops = self.lib.esahrnet_launch_count(h)
@@ -384,7 +395,7 @@ class _Runtime:
         dev = x.device
         heat = self.forward(module, x, keep=True)
         h = self.handles[dev.index][0]
-        _, ws_ptr, _ = self._workspace(h, dev, n, hh, ww, True)
+        _, ws_ptr, _ = self._workspace(h, dev, torch.cuda.current_stream(dev), n, hh, ww, True)
         out = {"heatmaps": heat}
         stream = torch.cuda.current_stream(dev).cuda_stream
         buf = C.create_string_buffer(96)
