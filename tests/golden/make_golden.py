@@ -52,24 +52,32 @@ def ref_cfg(widths, blocks):
 DEFAULT_BLOCKS = ((2,), (2, 2), (2, 2, 2), (4, 4, 4, 4))
 
 
-def build_ref(variant, widths, blocks, seed):
+def build_ref(variant, widths, blocks, seed, gain=0.5):
     mod = {"seg_hrnet": seg_hrnet, "seg_hrnet2": seg_hrnet2, "seg_hrnet3": seg_hrnet3}[variant]
     net = mod.get_seg_model(ref_cfg(widths, blocks)).eval()
-    sd = synth.make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=seed)
+    sd = synth.make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=seed, gain=gain)
     net.load_state_dict(sd, strict=True)
     return net, sd
 
 
-def full_net(tag, variant, widths, blocks, n, hw, seed, subsample=1, taps=False):
+def full_net(tag, variant, widths, blocks, n, hw, seed, subsample=1, taps=False, gain=0.5):
     cin = 3 if variant == "seg_hrnet" else 1
-    net, sd = build_ref(variant, widths, blocks, seed)
+    net, sd = build_ref(variant, widths, blocks, seed, gain)
     x = synth.make_crops(n, cin, hw, hw, seed=seed)
+    act_absmax = [0.0]
+
+    def hook(_m, _i, o):                                # largest activation any conv / BN / ReLU emits
+        if isinstance(o, torch.Tensor):
+            act_absmax[0] = max(act_absmax[0], float(o.abs().max()))
+    hooks = [m.register_forward_hook(hook) for m in net.modules() if not list(m.children())]
     with torch.no_grad():
         y = net(x)
+        for h_ in hooks:
+            h_.remove()
         y64 = net.double()(x.double())
     y = y.numpy()
     rec = dict(variant=variant, widths=np.asarray(widths), blocks_flat=np.asarray(sum(blocks, ())),
-               n=n, hw=hw, seed=seed, subsample=subsample,
+               n=n, hw=hw, seed=seed, subsample=subsample, gain=gain, act_absmax=act_absmax[0],
                out=y[:, :, ::subsample, ::subsample].copy(),
                out_absmax=np.abs(y).max(), out_sum=np.float64(y.astype(np.float64).sum()),
                plane_max=y.reshape(n, y.shape[1], -1).max(-1),
@@ -79,7 +87,7 @@ def full_net(tag, variant, widths, blocks, n, hw, seed, subsample=1, taps=False)
                state_keys=np.asarray(list(sd.keys())),
                state_shapes=np.asarray([",".join(map(str, v.shape)) for v in sd.values()]))
     np.savez_compressed(os.path.join(OUT, tag + ".npz"), **rec)
-    print(f"{tag}: out {y.shape} absmax {rec['out_absmax']:.4f} fp32-vs-fp64 Linf "
+    print(f"{tag}: out {y.shape} absmax {rec['out_absmax']:.4f} max|act| {act_absmax[0]:.2f} fp32-vs-fp64 Linf "
           f"{rec['fp32_vs_fp64_linf']:.3e}")
 
 
@@ -152,6 +160,10 @@ def adversarial_planes():
 def main():
     tiny = (8, 16, 32, 64)
     w32 = (32, 64, 128, 256)
+    if "--range" in sys.argv:       # dynamic-range goldens only (round 2): weight gain 1.0, SURVEY.md §8d
+        full_net("w32_hrnet2_128_g1", "seg_hrnet2", w32, DEFAULT_BLOCKS, 1, 128, seed=3, gain=1.0)
+        full_net("w32_hrnet2_256_g1", "seg_hrnet2", w32, DEFAULT_BLOCKS, 1, 256, seed=0, subsample=2, gain=1.0)
+        return
     full_net("tiny_hrnet2_64", "seg_hrnet2", tiny, DEFAULT_BLOCKS, 2, 64, seed=1)
     full_net("tiny_hrnet_64", "seg_hrnet", tiny, DEFAULT_BLOCKS, 1, 64, seed=2)
     full_net("w32_hrnet2_128", "seg_hrnet2", w32, DEFAULT_BLOCKS, 1, 128, seed=3)

@@ -138,16 +138,17 @@ def test_op_fuse_matches_torch_cpu(env):
 
 
 # ------------------------------------------------------------------------------------- full net
-def _build(env, variant, widths, seed):
+def _build(env, variant, widths, seed, gain=0.5, **kw):
     mod = env[variant]
-    net = mod.get_seg_model(env["config"].make_config(widths=widths))
-    sd = env["synth"].make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=seed)
+    net = mod.get_seg_model(env["config"].make_config(widths=widths), **kw)
+    sd = env["synth"].make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=seed, gain=gain)
     net.load_state_dict(sd, strict=True)
     return net.cuda().eval(), sd
 
 
 GOLDEN = ["tiny_hrnet2_64", "tiny_hrnet_64", "w32_hrnet2_128", "w32_hrnet2_256", "w32_hrnet_256",
-          "small_hrnet3_64", "w32_hrnet3_128"]       # the last two: seg_hrnet3 (CBAM), SURVEY.md §8a row a18
+          "small_hrnet3_64", "w32_hrnet3_128",       # seg_hrnet3 (CBAM), SURVEY.md §8a row a18
+          "w32_hrnet2_128_g1", "w32_hrnet2_256_g1"]  # weight gain 1.0: max|act| 66 / 79, |out| 13 / 20
 
 
 @pytest.mark.parametrize("tag", GOLDEN)
@@ -155,17 +156,19 @@ def test_full_net_matches_reference_golden(env, golden_dir, tag):
     """HIP forward vs the output of the REAL reference model (tests/golden/make_golden.py)."""
     g = np.load(os.path.join(golden_dir, tag + ".npz"), allow_pickle=False)
     variant = str(g["variant"])
-    net, sd = _build(env, variant, tuple(int(v) for v in g["widths"]), int(g["seed"]))
+    gain = float(g["gain"]) if "gain" in g.files else 0.5
+    net, sd = _build(env, variant, tuple(int(v) for v in g["widths"]), int(g["seed"]), gain)
     cin = 3 if variant == "seg_hrnet" else 1
     x = env["synth"].make_crops(int(g["n"]), cin, int(g["hw"]), int(g["hw"]), seed=int(g["seed"]))
     with torch.no_grad():
         y = net(x.cuda()).cpu().numpy()
     s = int(g["subsample"])
     err = np.abs(y[:, :, ::s, ::s] - g["out"]).max()
-    print(f"{tag}: Linf vs reference {err:.3e} (absmax {float(g['out_absmax']):.3f})")
+    print(f"{tag}: Linf vs reference {err:.3e} (absmax {float(g['out_absmax']):.3f}, reference fp32-vs-fp64 "
+          f"{float(g['fp32_vs_fp64_linf']):.2e})")
     assert np.isfinite(y).all()
-    assert err <= TOL, err
-    assert err <= GUARD, err
+    assert err <= TOL, err                                       # the contract: 1e-3 ABSOLUTE, at every magnitude
+    assert err <= GUARD * max(1.0, float(g["out_absmax"]) / 1.5), err    # regression guard, relative to the g=0.5 maps
     flat = y.reshape(y.shape[0], y.shape[1], -1)
     assert np.array_equal(flat.argmax(-1), g["plane_argmax"])
 
@@ -612,3 +615,59 @@ def test_keypoints_nan_policy_is_the_references(env):
     with np.errstate(all="ignore"):
         rc, rm = env["kref"].argmax_keypoints(hm)
     assert np.array_equal(preds, rc) and np.array_equal(np.isnan(maxvals[..., 0]), np.isnan(rm))
+
+
+# ------------------------------------------------------------------------------------- precision / configs (round 2)
+def test_w48_384_batch64_properties(env):
+    """BASELINE configs[3] workload (W48, 384x384, batch 64) in the split-bf16 arithmetic: crops are independent
+    (every sample equals its own batch-1 forward bit for bit, permutation equivariance), sample 0 vs the CPU
+    oracle, input untouched."""
+    net, sd = _build(env, "seg_hrnet2", (48, 96, 192, 384), 21)
+    synth = env["synth"]
+    x0 = synth.make_crops(1, 1, 384, 384, seed=21)
+    x = torch.cat([x0, synth.make_crops(63, 1, 384, 384, seed=77)]).cuda()
+    xc = x.clone()
+    cfg = env["hrnet_ref"].default_cfg(1, 11, widths=(48, 96, 192, 384))
+    with torch.no_grad():
+        ref = env["hrnet_ref"].forward(sd, cfg, x0)
+        y = net(x)
+        singles = {i: net(x[i:i + 1]) for i in (0, 13, 63)}
+        perm = torch.randperm(64, generator=torch.Generator().manual_seed(1)).cuda()
+        yp = net(x[perm])
+    torch.cuda.synchronize()
+    assert torch.equal(x, xc)
+    for i, ys in singles.items():
+        assert torch.equal(y[i:i + 1], ys), i
+    assert torch.equal(yp, y[perm])
+    err = (y[0:1].cpu() - ref).abs().max().item()
+    print(f"W48 384x384 batch 64: sample 0 Linf vs CPU oracle {err:.3e}")
+    assert err <= GUARD, err
+    kp = env["inference"].heatmaps_to_keypoints(y)
+    assert kp.shape == (64, 11, 3) and bool(torch.isfinite(kp).all())
+
+
+def test_dynamic_range_sweep(env):
+    """The tolerance is ABSOLUTE (1e-3) while the split-bf16 error is RELATIVE (~2^-17 per product), so the
+    margin shrinks as activations grow.  Sweep of the weight gain g (conv std = sqrt(g / fan_in))
+    at W32 128x128 against an fp64 evaluation of the oracle; beside it the error of the fp32 CPU reference itself
+    (at g = 2.0, He init, the reference's own fp32 noise passes 1e-3: SURVEY.md §8d).  Printed table -> DESIGN §3."""
+    cfg = env["hrnet_ref"].default_cfg(1, 11)
+    x = env["synth"].make_crops(1, 1, 128, 128, seed=3)
+    rows = []
+    for gain in (0.5, 1.0, 1.5, 2.0):
+        net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 3, gain)
+        taps = {}
+        with torch.no_grad():
+            ref64 = env["hrnet_ref"].forward(sd, cfg, x.double(), taps)
+            ref32 = env["hrnet_ref"].forward(sd, cfg, x)
+            y = net(x.cuda()).cpu().double()
+        act = max(float(t.abs().max()) for t in taps.values())
+        rows.append((gain, act, float(ref64.abs().max()), float((y - ref64).abs().max()),
+                     float((ref32.double() - ref64).abs().max())))
+    print("gain  max|act|  max|out|  HIP-vs-fp64  fp32ref-vs-fp64  HIP rel.")
+    for g_, act, out, e, e32 in rows:
+        print(f"{g_:4.1f}  {act:8.1f}  {out:8.2f}  {e:11.3e}  {e32:15.3e}  {e / out:8.2e}")
+    for g_, act, out, e, e32 in rows:
+        assert e / out <= 4.0e-5, (g_, e, out)          # relative error stays at the 2^-15..-16 level at every magnitude
+        if g_ <= 1.0:
+            assert e <= TOL, (g_, e)                    # the contract holds with margin at SURVEY's valid recipes
