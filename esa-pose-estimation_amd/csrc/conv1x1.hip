@@ -16,7 +16,9 @@
 namespace esa {
 namespace {
 
-template <int NCH>
+// BF (ConvParams::bf): NCH counts 64-channel blocks of 128 bytes; the (hi, lo) fragment pair of a chunk becomes the
+// two K-steps of a block (sb.h), 2 MFMAs instead of 3, and the epilogue packs 4 channels into 8 bytes.
+template <int NCH, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long ntiles, int tiles_per_row) {
     constexpr int WFR = 4 * NCH;                   // 1-KB weight fragments per 32-cout chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -35,9 +37,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long
     for (int c = 0; c < NCH; ++c) {
         uint4 h = make_uint4(0, 0, 0, 0), l = make_uint4(0, 0, 0, 0);
         if (valid) {
-            const char* a = p.x + ((size_t)row * p.W + col) * (size_t)(p.Cinp * 4) + c * 128 + g * 32;
+            const char* a = p.x + ((size_t)row * p.W + col) * (size_t)(p.Cinp * (BF ? 2 : 4)) + c * 128 + g * (BF ? 16 : 32);
             h = *reinterpret_cast<const uint4*>(a);
-            l = *reinterpret_cast<const uint4*>(a + 16);
+            l = *reinterpret_cast<const uint4*>(a + (BF ? 64 : 16));
         }
         xh[c] = __builtin_bit_cast(bf16x8, h);
         xl[c] = __builtin_bit_cast(bf16x8, l);
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long
     C1_PREFETCH(0)
     C1_COMMIT(0)
     __syncthreads();
-    char* orow = p.y + ((size_t)row * p.W + col) * (size_t)(p.Coutp * 4);
+    char* orow = p.y + ((size_t)row * p.W + col) * (size_t)(p.Coutp * (BF ? 2 : 4));
     for (int cc = 0; cc < nchunks; ++cc) {
         const int buf = cc & 1;
         if (cc + 1 < nchunks) C1_PREFETCH(cc + 1)
@@ -72,9 +74,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long
             for (int c = 0; c < NCH; ++c) {
                 const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wb + ((m * NCH + c) * 2 + 0) * 1024);
                 const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wb + ((m * NCH + c) * 2 + 1) * 1024);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[c], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[c], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[c], d, 0, 0, 0);
+                if (BF) {
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[c], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl[c], d, 0, 0, 0);
+                } else {
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[c], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[c], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[c], d, 0, 0, 0);
+                }
             }
             float v[4] = {d[0], d[1], d[2], d[3]};
             {
@@ -82,10 +89,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = relu_opt(v[r], rfl);
             }
-            uint2 hi, lo;
-            split4(v, hi, lo);
-            const uint4 ch = quad_to_chunk(hi, lo);
-            if (valid) *reinterpret_cast<uint4*>(orow + chunk_ofs(co, g)) = ch;
+            if (BF) {
+                if (valid) *reinterpret_cast<uint2*>(orow + co * 2) = pack4_bf16(v);
+            } else {
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                const uint4 ch = quad_to_chunk(hi, lo);
+                if (valid) *reinterpret_cast<uint4*>(orow + chunk_ofs(co, g)) = ch;
+            }
         }
         if (cc + 1 < nchunks) {
             C1_COMMIT(buf ^ 1)
@@ -96,9 +107,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long
 #undef C1_COMMIT
 }
 
-template <int NCH>
+template <int NCH, bool BF = false>
 int launch_conv1x1_n(const ConvParams& p, hipStream_t stream) {
-    auto kern = conv1x1_kernel<NCH>;
+    auto kern = conv1x1_kernel<NCH, BF>;
     const int lds = 2 * 4 * NCH * 1024;
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const int tiles_per_row = (p.W + 15) / 16;
@@ -114,6 +125,11 @@ int launch_conv1x1_n(const ConvParams& p, hipStream_t stream) {
 // weights must be packed with pack_conv_weights(k = 1): [Coutp/16][Cinp/32][hi|lo][64] fragments — the
 // 4*NCH fragments of a 32-cout chunk are contiguous, which is what the staging above relies on
 bool conv1x1_supported(const ConvParams& p) {
+    if (p.bf) {         // blocks of 64 input channels; every width of the BF plans (64 .. 768 channels)
+        const int n = p.Cinp / 64;
+        return (p.Cinp % 64) == 0 && (p.Coutp % 64) == 0 && !p.res && !p.out_f32 && p.H == p.OH && p.W == p.OW &&
+               (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12);
+    }
     const int n = p.Cinp / 32;
     return (p.Cinp % 32) == 0 && (p.Coutp % 32) == 0 && !p.res && !p.out_f32 && p.H == p.OH && p.W == p.OW &&
            (n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12);
@@ -121,6 +137,18 @@ bool conv1x1_supported(const ConvParams& p) {
 
 int launch_conv1x1(const ConvParams& p, hipStream_t stream) {
     if (!conv1x1_supported(p)) return (int)hipErrorInvalidValue;
+    if (p.bf) {
+        switch (p.Cinp / 64) {
+            case 1: return launch_conv1x1_n<1, true>(p, stream);
+            case 2: return launch_conv1x1_n<2, true>(p, stream);
+            case 3: return launch_conv1x1_n<3, true>(p, stream);
+            case 4: return launch_conv1x1_n<4, true>(p, stream);
+            case 6: return launch_conv1x1_n<6, true>(p, stream);
+            case 8: return launch_conv1x1_n<8, true>(p, stream);
+            case 12: return launch_conv1x1_n<12, true>(p, stream);
+        }
+        return (int)hipErrorInvalidValue;
+    }
     switch (p.Cinp / 32) {
         case 2: return launch_conv1x1_n<2>(p, stream);
         case 3: return launch_conv1x1_n<3>(p, stream);

@@ -524,6 +524,12 @@ namespace {
 // bit-identical in any batch (tests/test_gpu_parity.py).
 enum Choice { C_NONE, C_STREAM_S1, C_TILE_S1_8, C_TILE_S1_16, C_STREAM_S2, C_TILE_S2, C_1X1, C_TILE_1X1 };
 Choice choose_conv(const ConvParams& p, int k, int stride) {
+    if (p.bf) {         // single-bf16 tensors: the stream kernel (every 3x3) and the register 1x1 kernel only
+        if (k == 3 && stride == 1) return conv_s2c32_supported(p) ? C_STREAM_S1 : C_NONE;
+        if (k == 3 && stride == 2) return conv_s2c32_supported(p) ? C_STREAM_S2 : C_NONE;
+        if (k == 1 && stride == 1) return conv1x1_supported(p) ? C_1X1 : C_NONE;
+        return C_NONE;
+    }
     if ((p.Cinp & 31) || (p.Coutp & 31)) return C_NONE;
     // one image is addressed with 32-bit byte offsets inside the kernels
     if ((long long)p.H * p.W * p.Cinp * 4 > 0x7fffffffLL) return C_NONE;
@@ -567,6 +573,14 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
 const char* conv_kernel_name(const ConvParams& p, int k, int stride) {
     const bool ring = ESA_CONV_RING && p.Cinp > 32;
     const bool persist = p.Cinp == 32;
+    if (p.bf) {
+        switch (choose_conv(p, k, stride)) {
+            case C_STREAM_S1: return "conv_s2c32_kernel<1, 8, 4, false, true>";
+            case C_STREAM_S2: return "conv_s2c32_kernel<2, 4, 4, false, true>";
+            case C_1X1: return "conv1x1_kernel<bf16>";
+            default: return "none";
+        }
+    }
     switch (choose_conv(p, k, stride)) {
         case C_STREAM_S1: return p.Coutp % 64 == 0 ? "conv_s2c32_kernel<1, 8, 4, false>" : "conv_s2c32_kernel<1, 8, 2, false>";
         case C_TILE_S1_8: return ring ? "conv_mfma_ring_kernel<1, 8, 2>" : persist ? "conv_mfma_kernel<3, 1, 8, 2, true>" : "conv_mfma_kernel<3, 1, 8, 2, false>";
@@ -615,6 +629,27 @@ void pack_conv_weights(const float* w, int cout, int cin, int k, int coutp, int 
                         d[base + l * 8 + j] = hi;
                         d[base + 512 + l * 8 + j] = lo;
                     }
+}
+
+size_t packed_weight_bytes_bf(int coutp, int cinp, int k) {
+    return (size_t)(coutp / 16) * (cinp / 64) * k * k * 2048;
+}
+
+// BF mode (kernels.h): [cout16 tile][cin64 block][tap][K-step][lane 0..63][8 x bf16]; one rounding per weight
+void pack_conv_weights_bf(const float* w, int cout, int cin, int k, int coutp, int cinp, void* dst) {
+    uint16_t* d = static_cast<uint16_t*>(dst);
+    const int taps = k * k, nblk = cinp / 64;
+    for (int t16 = 0; t16 < coutp / 16; ++t16)
+        for (int c = 0; c < nblk; ++c)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int step = 0; step < 2; ++step)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = t16 * 16 + (l & 15), ci = c * 64 + step * 32 + 8 * (l >> 4) + j;
+                            float v = 0.f;
+                            if (co < cout && ci < cin) v = w[((size_t)co * cin + ci) * taps + tap];
+                            d[(((((size_t)t16 * nblk + c) * taps + tap) * 2) + step) * 512 + l * 8 + j] = host_bf16(v);
+                        }
 }
 
 }  // namespace esa

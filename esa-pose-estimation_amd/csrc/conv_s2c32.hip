@@ -89,7 +89,11 @@ __device__ __forceinline__ int div_magic(int b, int d, uint32_t m) {
 // VGPRs).  Single-chunk layers whose cout slice does not change keep their weights for the whole launch.
 // MH: multi-head launch (ConvParams::nheads > 1): the output tensor, its channel count and the ReLU flag depend on
 // the cout slice of the item.
-template <int S, int TH, int MW, bool MH = false>
+// BF: the tensors are single bf16 (sb.h "BF", esahrnet_cfg.precision 1).  A step stages one 128-byte block of 64
+// channels per pixel — the same loads, planes and reads as a 32-channel split chunk — whose plane pair (2g, 2g+1) holds
+// the block's two MFMA K-steps instead of (hi, lo); the weight registers wh / wl hold the K-step 0 / 1 fragments; a
+// tap of a row is 2 MFMAs for 64 channels instead of 3 for 32; accumulators leave as 8 bytes of bf16 per lane.
+template <int S, int TH, int MW, bool MH = false, bool BF = false>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, StreamGeo geo) {
     using S2C = ConvCfg<3, S, TH, 2>;
     constexpr int RG = 4 / MW;                  // row groups
@@ -106,9 +110,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
     const int g = lane >> 4;
     const int mw = wave % MW, rg = wave / MW;
     const int G = gridDim.x;
-    const int nchunks = p.Cinp >> 5;
-    const int pixb = p.Cinp * 4;
-    int opix = p.Coutp * 4;                                              // (per item in a multi-head launch)
+    constexpr int EB = BF ? 2 : 4;             // bytes per channel
+    const int nchunks = p.Cinp >> (BF ? 6 : 5);
+    const int pixb = p.Cinp * EB;
+    int opix = p.Coutp * EB;                                             // (per item in a multi-head launch)
     const int ximg = p.H * p.W * pixb;
     int yimg = p.OH * p.OW * opix;                                       // bytes per image (< 2^31, host-checked)
     int item = xcd_contiguous(blockIdx.x, G);
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
 
     // ---- staging map: thread -> (operand plane jst, tile pixel q0 + 32*it), fixed for the launch ----
     const int jst = tid & 7, q0 = tid >> 3;
-    char* xwr = xs + S2C::plane_off(jst) + q0 * 16;
+    char* xwr = xs + S2C::plane_off(BF ? bf_plane_of_chunk(jst) : jst) + q0 * 16;
     int qyx[S2C::XITER];                        // tile-local (row << 8 | column) of the pixel, -1 beyond the tile
 #pragma unroll
     for (int it = 0; it < S2C::XITER; ++it) {
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
             const int cb = (ct * MW + mw) * 16;                 // per wave: a 64-cout slice may span two heads
             const int hsel = (cb >= p.hb[1] ? 1 : 0) + (p.nheads > 2 && cb >= p.hb[2] ? 1 : 0);
             co -= p.hb[hsel];
-            opix = (p.hb[hsel + 1] - p.hb[hsel]) * 4;
+            opix = (p.hb[hsel + 1] - p.hb[hsel]) * EB;
             yimg = p.OH * p.OW * opix;
             ry = make_rsrc(p.yh[hsel], (uint32_t)p.N * (uint32_t)yimg);
             relu = p.hrelu[hsel];
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
         }
         // output rows of this wave: 32-bit offsets inside the image, OOB for pixels outside it
         const int rox = ox0 + (lane & 15), roy = oy0 + rg * NT;
-        const uint32_t o0 = rox < p.OW ? (uint32_t)((roy * p.OW + rox) * opix + chunk_ofs(co, g)) : OOB;
+        const uint32_t o0 = rox < p.OW ? (uint32_t)((roy * p.OW + rox) * opix + (BF ? co * 2 : chunk_ofs(co, g))) : OOB;
         const int orow = p.OW * opix, yso = n * yimg;
         const int nrows = p.OH - roy;                                   // rows t < nrows exist
         // residual (last chunk only): the first half of the wave's rows is loaded at the start of the step and folded
@@ -254,10 +259,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
             for (int t = 0; t < NH; ++t) {
                 const int tt = half * NH + t;
                 const uint32_t ro_ = (tt < NT && tt < nrows) ? o0 + (uint32_t)(tt * orow) : OOB;
-                rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ro_, yso, 0);
+                if (BF) {
+                    const auto r2 = __builtin_amdgcn_raw_buffer_load_b64(rr, (int)ro_, yso, 0);
+                    rc[t] = u32x4{r2[0], r2[1], 0u, 0u};
+                } else {
+                    rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ro_, yso, 0);
+                }
             }
         };
         auto res_of = [&](int t, float r_[4]) __attribute__((always_inline)) {
+            if (BF) {
+                unpack4_bf16(make_uint2(rc[t][0], rc[t][1]), r_);
+                return;
+            }
             uint2 rh_, rl_;
             chunk_to_quad(make_uint4(rc[t][0], rc[t][1], rc[t][2], rc[t][3]), rh_, rl_);
             join4(rh_, rl_, r_);
@@ -272,11 +286,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = relu_opt(v[i], rfl);
+            const uint32_t so_ = t < nrows ? o0 + (uint32_t)(t * orow) : OOB;
+            if (BF) {       // 4 channels of one pixel = 8 bytes per lane; the four rows of 16 lanes fill 32 contiguous bytes
+                typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+                const uint2 pk = pack4_bf16(v);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, ry, (int)(so_ + (uint32_t)yso), 0, 0);
+                return;
+            }
             uint2 hi, lo;
             split4(v, hi, lo);
             const uint4 ch = quad_to_chunk(hi, lo);
             const u32x4 cv = {ch.x, ch.y, ch.z, ch.w};
-            const uint32_t so_ = t < nrows ? o0 + (uint32_t)(t * orow) : OOB;
             // The image base goes into the VECTOR offset, the scalar offset stays the constant 0: gfx950 reads the
             // data registers of a 16-byte buffer store late (lanes 12..15 of every row of 16), so the instruction
             // behind it must not overwrite them — and hipcc 7.2 pads that hazard only for stores WITHOUT an
@@ -320,9 +340,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
                     const int d = i - ky;
                     if (!(S2_ABL & 8) && d >= 0 && d % S == 0 && d / S < NT) {
                         const int t = d / S;
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ky * 3 + kx], xh, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xo, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xh, acc[t], 0, 0, 0);
+                        if (BF) {
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xh, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ky * 3 + kx], xo, acc[t], 0, 0, 0);
+                        } else {
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ky * 3 + kx], xh, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xo, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xh, acc[t], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -397,34 +422,36 @@ uint32_t magic_of(int d) { return (uint32_t)(0xffffffffull / (uint64_t)d); }
 // layer — and with it every bit of a crop's result — never depends on the batch size.
 std::atomic<long long> g_launch_limit{0x7fffffffLL};      // bytes; lowered only by tests (esahrnet_debug_set_launch_limit)
 int images_per_launch(const ConvParams& p) {
-    long long per = (long long)p.H * p.W * p.Cinp * 4;
+    const int eb = p.bf ? 2 : 4;
+    long long per = (long long)p.H * p.W * p.Cinp * eb;
     if (p.nheads > 1) {
-        for (int h = 0; h < p.nheads; ++h) per = std::max(per, (long long)p.OH * p.OW * (p.hb[h + 1] - p.hb[h]) * 4);
+        for (int h = 0; h < p.nheads; ++h) per = std::max(per, (long long)p.OH * p.OW * (p.hb[h + 1] - p.hb[h]) * eb);
     } else {
-        per = std::max(per, (long long)p.OH * p.OW * p.Coutp * 4);
+        per = std::max(per, (long long)p.OH * p.OW * p.Coutp * eb);
     }
     return (int)std::min<long long>(p.N, g_launch_limit.load(std::memory_order_relaxed) / std::max(per, 1LL));
 }
 
-template <int S, int TH, int MW, bool MH = false>
+template <int S, int TH, int MW, bool MH = false, bool BF = false>
 int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
     using S2C = ConvCfg<3, S, TH, 2>;
+    constexpr int EB = BF ? 2 : 4;
     const int nmax = images_per_launch(p);
     if (nmax < 1) return (int)hipErrorInvalidValue;
     if (p.N > nmax) {
         for (int n0 = 0; n0 < p.N; n0 += nmax) {
             ConvParams q = p;
             q.N = std::min(nmax, p.N - n0);
-            q.x = p.x + (size_t)n0 * p.H * p.W * p.Cinp * 4;
-            if (p.y) q.y = p.y + (size_t)n0 * p.OH * p.OW * p.Coutp * 4;
-            if (p.res) q.res = p.res + (size_t)n0 * p.OH * p.OW * p.Coutp * 4;
+            q.x = p.x + (size_t)n0 * p.H * p.W * p.Cinp * EB;
+            if (p.y) q.y = p.y + (size_t)n0 * p.OH * p.OW * p.Coutp * EB;
+            if (p.res) q.res = p.res + (size_t)n0 * p.OH * p.OW * p.Coutp * EB;
             for (int h = 0; h < p.nheads && h < 3; ++h)
-                if (p.yh[h]) q.yh[h] = p.yh[h] + (size_t)n0 * p.OH * p.OW * (p.hb[h + 1] - p.hb[h]) * 4;
-            if (const int e = launch_s2c32_t<S, TH, MW, MH>(q, stream)) return e;
+                if (p.yh[h]) q.yh[h] = p.yh[h] + (size_t)n0 * p.OH * p.OW * (p.hb[h + 1] - p.hb[h]) * EB;
+            if (const int e = launch_s2c32_t<S, TH, MW, MH, BF>(q, stream)) return e;
         }
         return 0;
     }
-    auto kern = conv_s2c32_kernel<S, TH, MW, MH>;
+    auto kern = conv_s2c32_kernel<S, TH, MW, MH, BF>;
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), S2C::XBYTES)) return e_;
     StreamGeo geo;
     geo.tiles_x = (p.OW + TW - 1) / TW;
@@ -453,6 +480,8 @@ void set_stream_launch_limit(long long bytes) {
 // one IMAGE must be addressable with 31-bit byte offsets (buffer descriptors, OOB marker 2^31); a batch that is not
 // is cut into image ranges by the launcher (images_per_launch), so this predicate does not look at N
 bool conv_s2c32_supported(const ConvParams& p) {
+    if (p.bf) return (p.Cinp & 63) == 0 && p.Cinp >= 64 && (p.Coutp & 63) == 0 && !p.out_f32 && p.nheads <= 1 &&
+                     (long long)p.H * p.W * p.Cinp * 2 < 0x7fffffffLL && (long long)p.OH * p.OW * p.Coutp * 2 < 0x7fffffffLL;
     return (p.Cinp & 31) == 0 && p.Cinp >= 32 && (p.Coutp & 31) == 0 && !p.out_f32 &&
            (long long)p.H * p.W * p.Cinp * 4 < 0x7fffffffLL &&
            (long long)p.OH * p.OW * p.Coutp * 4 < 0x7fffffffLL;
@@ -460,10 +489,12 @@ bool conv_s2c32_supported(const ConvParams& p) {
 
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream) {
     if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
+    if (p.bf) return launch_s2c32_t<2, 4, 4, false, true>(p, stream);
     return (p.Coutp % 64 == 0) ? launch_s2c32_t<2, 4, 4>(p, stream) : launch_s2c32_t<2, 4, 2>(p, stream);
 }
 
 bool conv_s2c32_multi_supported(const ConvParams& p) {
+    if (p.bf) return false;
     if (p.nheads < 2 || p.nheads > 3 || p.res || p.out_f32 || p.hb[0] != 0 || p.hb[p.nheads] != p.Coutp) return false;
     if ((p.Cinp & 31) || p.Cinp < 32 || (long long)p.H * p.W * p.Cinp * 4 >= 0x7fffffffLL) return false;
     for (int h = 0; h < p.nheads; ++h) {
@@ -484,6 +515,7 @@ int launch_conv_s2c32_multi(const ConvParams& p, hipStream_t stream) {
 // 256 VGPRs and was 4-14 % slower)
 int launch_conv_s1w(const ConvParams& p, hipStream_t stream) {
     if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
+    if (p.bf) return launch_s2c32_t<1, 8, 4, false, true>(p, stream);
     if (p.Coutp % 64 == 0) return launch_s2c32_t<1, 8, 4>(p, stream);
     return launch_s2c32_t<1, 8, 2>(p, stream);
 }

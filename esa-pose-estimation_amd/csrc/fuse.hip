@@ -58,7 +58,17 @@ struct FuseScales {
 // One workgroup row = one output row (blockIdx.y = n*H + y): the row decomposition and the vertical
 // interpolation are wave-uniform, all per-lane index math is 32-bit.  NS same-resolution terms come
 // first, then NU lower-resolution terms (the host orders them); both counts are compile-time.
-template <int NS, int NU>
+// one 8-channel group of a pixel -> 8 floats (SB: hi + lo chunks, 32 bytes; BF: one 16-byte chunk)
+template <bool BF>
+__device__ __forceinline__ void load8(const char* pix, int c8, float v[8]) {
+    if (BF) {
+        unpack8_bf16(*reinterpret_cast<const uint4*>(pix + c8 * 16), v);
+    } else {
+        join8(*reinterpret_cast<const uint4*>(pix + c8 * 32), *reinterpret_cast<const uint4*>(pix + c8 * 32 + 16), v);
+    }
+}
+
+template <int NS, int NU, bool BF = false>
 __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) {
     const int G = p.Cp >> 3;
     const unsigned u = blockIdx.x * 256u + threadIdx.x;
@@ -67,12 +77,11 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) 
     const int c8 = (int)(u - (unsigned)x * (unsigned)G);
     const int row = blockIdx.y;                   // n*H + y
     const int n = row / p.H, y = row - n * p.H;
-    const int pixb = p.Cp * 4;
+    const int pixb = p.Cp * (BF ? 2 : 4);
 
     float acc[8];
     if (NS > 0) {
-        const char* a = p.x[0] + ((size_t)row * p.W + x) * (size_t)pixb + c8 * 32;
-        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), acc);
+        load8<BF>(p.x[0] + ((size_t)row * p.W + x) * (size_t)pixb, c8, acc);
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -80,8 +89,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) 
 #pragma unroll
     for (int t = 1; t < NS; ++t) {
         float v[8];
-        const char* a = p.x[t] + ((size_t)row * p.W + x) * (size_t)pixb + c8 * 32;
-        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+        load8<BF>(p.x[t] + ((size_t)row * p.W + x) * (size_t)pixb, c8, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += v[i];
     }
@@ -90,14 +98,14 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) 
         const int t = NS + k;
         const int h = p.h[t], w = p.w[t];
         const Lerp ly = lerp_scaled(y, h, fs.sy[t]), lx = lerp_scaled(x, w, fs.sx[t]);
-        const char* r0 = p.x[t] + ((size_t)n * h + ly.i0) * w * (size_t)pixb + c8 * 32;
-        const char* r1 = p.x[t] + ((size_t)n * h + ly.i1) * w * (size_t)pixb + c8 * 32;
+        const char* r0 = p.x[t] + ((size_t)n * h + ly.i0) * w * (size_t)pixb;
+        const char* r1 = p.x[t] + ((size_t)n * h + ly.i1) * w * (size_t)pixb;
         const int o0 = lx.i0 * pixb, o1 = lx.i1 * pixb;
         float v00[8], v01[8], v10[8], v11[8];
-        join8(*reinterpret_cast<const uint4*>(r0 + o0), *reinterpret_cast<const uint4*>(r0 + o0 + 16), v00);
-        join8(*reinterpret_cast<const uint4*>(r0 + o1), *reinterpret_cast<const uint4*>(r0 + o1 + 16), v01);
-        join8(*reinterpret_cast<const uint4*>(r1 + o0), *reinterpret_cast<const uint4*>(r1 + o0 + 16), v10);
-        join8(*reinterpret_cast<const uint4*>(r1 + o1), *reinterpret_cast<const uint4*>(r1 + o1 + 16), v11);
+        load8<BF>(r0 + o0, c8, v00);
+        load8<BF>(r0 + o1, c8, v01);
+        load8<BF>(r1 + o0, c8, v10);
+        load8<BF>(r1 + o1, c8, v11);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             acc[i] += ly.l0 * (lx.l0 * v00[i] + lx.l1 * v01[i]) + ly.l1 * (lx.l0 * v10[i] + lx.l1 * v11[i]);
@@ -105,6 +113,10 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) 
     if (p.relu) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = relu1(acc[i]);
+    }
+    if (BF) {
+        *reinterpret_cast<uint4*>(p.y + ((size_t)row * p.W + x) * (size_t)pixb + c8 * 16) = pack8_bf16(acc);
+        return;
     }
     uint4 hi, lo;
     split8(acc, hi, lo);
@@ -118,7 +130,9 @@ int launch_fuse_t(const FuseParams& p, const FuseScales& fs, hipStream_t stream)
     const long long per_row = (long long)p.W * (p.Cp >> 3);
     const long long rows = (long long)p.N * p.H;
     if (per_row <= 0 || rows <= 0 || rows > 0x7fffffffLL || per_row > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((fuse_kernel<NS, NU>), dim3((unsigned)((per_row + 255) / 256), (unsigned)rows), dim3(256), 0, stream, p, fs);
+    const dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)rows);
+    if (p.bf) hipLaunchKernelGGL((fuse_kernel<NS, NU, true>), grid, dim3(256), 0, stream, p, fs);
+    else hipLaunchKernelGGL((fuse_kernel<NS, NU, false>), grid, dim3(256), 0, stream, p, fs);
     return (int)hipGetLastError();
 }
 

@@ -59,17 +59,20 @@ __global__ __launch_bounds__(256) void final_kernel(FinalParams p, int tiles_x, 
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
             const LerpT ly = lerp_ac_true(gy, p.h, p.H), lx = lerp_ac_true(gx, p.wd, p.W);
             const size_t r0 = ((size_t)n * p.h + ly.i0) * p.wd, r1 = ((size_t)n * p.h + ly.i1) * p.wd;
-            const size_t ps = (size_t)p.Cp * 4;
+            const size_t ps = (size_t)p.Cp * (p.bf ? 2 : 4);
             float v00[8], v01[8], v10[8], v11[8];
-            const char* a;
-            a = p.h3 + (r0 + lx.i0) * ps + c8 * 32;
-            join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v00);
-            a = p.h3 + (r0 + lx.i1) * ps + c8 * 32;
-            join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v01);
-            a = p.h3 + (r1 + lx.i0) * ps + c8 * 32;
-            join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v10);
-            a = p.h3 + (r1 + lx.i1) * ps + c8 * 32;
-            join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v11);
+            auto ld = [&](size_t pix, float v_[8]) {
+                if (p.bf) {
+                    unpack8_bf16(*reinterpret_cast<const uint4*>(p.h3 + pix * ps + c8 * 16), v_);
+                } else {
+                    const char* a = p.h3 + pix * ps + c8 * 32;
+                    join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v_);
+                }
+            };
+            ld(r0 + lx.i0, v00);
+            ld(r0 + lx.i1, v01);
+            ld(r1 + lx.i0, v10);
+            ld(r1 + lx.i1, v11);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 v[i] = ly.l0 * (lx.l0 * v00[i] + lx.l1 * v01[i]) + ly.l1 * (lx.l0 * v10[i] + lx.l1 * v11[i]);

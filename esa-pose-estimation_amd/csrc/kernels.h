@@ -19,6 +19,8 @@ struct ConvParams {
     int Cinp, Coutp;    // multiples of 32
     int relu;
     int out_f32;        // 0: y is SB; 1: y is plain f32 NHWC [N][OH][OW][Coutp] (head terms t_b)
+    int bf;             // 1: x, y, res are BF tensors (single bf16, sb.h), Cinp / Coutp multiples of 64, weights packed
+                        //    by pack_conv_weights_bf; served by the stream kernel (3x3) and conv1x1 only
     // multi-head form (stream kernel, stride 2 only): several convolutions of the SAME input evaluated in one launch —
     // w / bias are the members' packed weights / biases concatenated along cout, Coutp their total, and head h
     // (couts hb[h] .. hb[h+1]-1 of the concatenation, multiples of 32) goes to its own SB tensor yh[h] of
@@ -47,6 +49,11 @@ int launch_conv1x1(const ConvParams& p, hipStream_t stream);
 size_t packed_weight_bytes(int coutp, int cinp, int k);
 // host-side packing: w f32 [cout][cin][k][k] -> dst (packed_weight_bytes), zero padded
 void pack_conv_weights(const float* w, int cout, int cin, int k, int coutp, int cinp, void* dst);
+// BF mode: [cout16 tile][cin64 block][tap][K-step 0|1][lane][8 x bf16], lane l holding
+// W[tile*16 + (l&15)][block*64 + step*32 + 8*(l>>4) + j] rounded to bf16 — same fragment count and order as the
+// split format has for twice the channels per block
+size_t packed_weight_bytes_bf(int coutp, int cinp, int k);
+void pack_conv_weights_bf(const float* w, int cout, int cin, int k, int coutp, int cinp, void* dst);
 
 // ---- stem conv1: f32 NCHW -> SB, 3x3 s1, cin in {1..4}, cout = multiple of 32 (stem.hip) ---
 struct StemParams {
@@ -56,6 +63,7 @@ struct StemParams {
     const float* bias;  // f32 [cout]
     int N, H, W, cin, cout;
     int relu;           // 0: raw conv output (seg_hrnet3 keeps the pre-BN conv1 tensor for its skip)
+    int bf;             // 1: y is a BF tensor (cout = padded channel count, multiple of 64)
 };
 int launch_stem(const StemParams& p, hipStream_t stream);
 
@@ -91,6 +99,7 @@ struct FuseParams {
     char* y;
     int N, H, W, Cp;
     int relu;
+    int bf;             // 1: all tensors are BF
 };
 int launch_fuse(const FuseParams& p, hipStream_t stream);
 
@@ -104,6 +113,7 @@ struct FinalParams {
     const uint4* wpk;   // MFMA path: split-bf16 fragments (pack_final_mfma), or nullptr -> VALU kernel
     int N, H, W, h, wd; // h,wd = resolution of h3
     int K, cin, Cp;
+    int bf;             // 1: h3 is a BF tensor (VALU kernel only)
 };
 int launch_final(const FinalParams& p, hipStream_t stream);
 bool final_mfma_supported(int K, int cin);
@@ -193,5 +203,8 @@ int launch_crops(const unsigned char* frames, const int* boxes, float* out, int 
 // ---- layout conversion f32 NCHW <-> SB (layout.hip) ----------------------------------------
 int launch_nchw_to_sb(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s);
 int launch_sb_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s);
+// the same for BF tensors (single bf16 NHWC, sb.h)
+int launch_nchw_to_bf(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s);
+int launch_bf_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s);
 
 }  // namespace esa

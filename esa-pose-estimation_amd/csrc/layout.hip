@@ -7,6 +7,7 @@
 namespace esa {
 namespace {
 
+template <bool BF>
 __global__ __launch_bounds__(256) void nchw_to_sb_kernel(const float* x, int N, int C, int H, int W,
                                                          char* y, int Cp, long long total) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -23,6 +24,10 @@ __global__ __launch_bounds__(256) void nchw_to_sb_kernel(const float* x, int N, 
         const int c = c8 * 8 + i;
         v[i] = c < C ? x[((size_t)n * C + c) * hw + s] : 0.f;
     }
+    if (BF) {
+        *reinterpret_cast<uint4*>(y + (size_t)pix * (size_t)(Cp * 2) + c8 * 16) = pack8_bf16(v);
+        return;
+    }
     uint4 hi, lo;
     split8(v, hi, lo);
     char* o = y + (size_t)pix * (size_t)(Cp * 4) + c8 * 32;
@@ -30,6 +35,7 @@ __global__ __launch_bounds__(256) void nchw_to_sb_kernel(const float* x, int N, 
     *reinterpret_cast<uint4*>(o + 16) = lo;
 }
 
+template <bool BF>
 __global__ __launch_bounds__(256) void sb_to_nchw_kernel(const char* x, int N, int C, int H, int W,
                                                          int Cp, float* y, long long total) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over (n, c, s), s fastest
@@ -39,6 +45,10 @@ __global__ __launch_bounds__(256) void sb_to_nchw_kernel(const char* x, int N, i
     const long long nc = idx / hw;
     const int c = (int)(nc % C);
     const int n = (int)(nc / C);
+    if (BF) {
+        y[idx] = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(x + ((size_t)n * hw + s) * (size_t)(Cp * 2) + c * 2));
+        return;
+    }
     const char* a = x + ((size_t)n * hw + s) * (size_t)(Cp * 4) + (c >> 3) * 32 + (c & 7) * 2;
     const uint32_t hi = *reinterpret_cast<const unsigned short*>(a);
     const uint32_t lo = *reinterpret_cast<const unsigned short*>(a + 16);
@@ -51,7 +61,15 @@ int launch_nchw_to_sb(const float* x, int N, int C, int H, int W, char* y, int C
     const long long total = (long long)N * H * W * (Cp >> 3);
     const long long nblk = (total + 255) / 256;
     if (nblk <= 0 || nblk > 0x7fffffffLL || (Cp & 7) || C > Cp) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(nchw_to_sb_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, N, C, H, W, y, Cp, total);
+    hipLaunchKernelGGL(nchw_to_sb_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, x, N, C, H, W, y, Cp, total);
+    return (int)hipGetLastError();
+}
+
+int launch_nchw_to_bf(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s) {
+    const long long total = (long long)N * H * W * (Cp >> 3);
+    const long long nblk = (total + 255) / 256;
+    if (nblk <= 0 || nblk > 0x7fffffffLL || (Cp & 7) || C > Cp) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(nchw_to_sb_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, x, N, C, H, W, y, Cp, total);
     return (int)hipGetLastError();
 }
 
@@ -59,7 +77,15 @@ int launch_sb_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* 
     const long long total = (long long)N * C * H * W;
     const long long nblk = (total + 255) / 256;
     if (nblk <= 0 || nblk > 0x7fffffffLL || C > Cp) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(sb_to_nchw_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, N, C, H, W, Cp, y, total);
+    hipLaunchKernelGGL(sb_to_nchw_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, x, N, C, H, W, Cp, y, total);
+    return (int)hipGetLastError();
+}
+
+int launch_bf_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s) {
+    const long long total = (long long)N * C * H * W;
+    const long long nblk = (total + 255) / 256;
+    if (nblk <= 0 || nblk > 0x7fffffffLL || C > Cp) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sb_to_nchw_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, x, N, C, H, W, Cp, y, total);
     return (int)hipGetLastError();
 }
 

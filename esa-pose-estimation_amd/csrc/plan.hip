@@ -51,6 +51,7 @@ int fail(const char* fmt, ...) {
     } while (0)
 
 inline int pad32(int c) { return (c + 31) & ~31; }
+inline int pad64(int c) { return (c + 63) & ~63; }
 
 struct ConvSpec {               // one Conv2d of the reference module tree
     std::string name, bn;
@@ -158,6 +159,9 @@ struct esahrnet_ctx {
     float *head_b0 = nullptr, *head_b3 = nullptr;
     bool committed = false;
     bool keep = false;
+    bool bf = false;            // cfg.precision == 1: tensors are single bf16 (sb.h "BF"), channels padded to 64
+    int padc(int ch) const { return bf ? pad64(ch) : pad32(ch); }
+    int eb() const { return bf ? 2 : 4; }       // bytes per stored channel
     bool fuse_big = true;       // fused stem + fused head (ESAHRNET_UNFUSED=1 selects the op-by-op plan)
     bool head2_enabled = true;  // ESAHRNET_HEAD_V1=1 keeps the first-generation fused head for every shape
     int head2_op = -1;          // index of the OP_HEAD2 op, -1 if the plan has none
@@ -192,7 +196,7 @@ struct Builder {
     }
     int tensor(int C, int level, const std::string& tap = "") {
         Tensor t;
-        t.C = C; t.Cp = pad32(C); t.level = level; t.tap = tap;
+        t.C = C; t.Cp = c.padc(C); t.level = level; t.tap = tap;
         c.tensors.push_back(t);
         return (int)c.tensors.size() - 1;
     }
@@ -206,7 +210,7 @@ struct Builder {
         const ConvSpec& s = c.specs[sp];
         DevConv d;
         d.spec = sp; d.c0 = c0; d.c1 = c1 < 0 ? s.cin : c1; d.use_bias = use_bias; d.out_f32 = out_f32;
-        d.cinp = pad32(d.c1 - d.c0); d.coutp = pad32(s.cout);
+        d.cinp = c.padc(d.c1 - d.c0); d.coutp = c.padc(s.cout);
         c.dconvs.push_back(d);
         Op o;
         o.kind = OP_CONV; o.dconv = (int)c.dconvs.size() - 1; o.in = in; o.res = res; o.relu = relu; o.lane = lane;
@@ -317,7 +321,7 @@ struct Builder {
 // Post-pass over the op list: find the stride-2 3x3 convolutions that share their input and make each such group
 // consecutive (moving a member EARLIER is always legal: its only input is defined before the group's first member).
 void group_multihead(esahrnet_ctx& c) {
-    if (getenv("ESAHRNET_NO_MULTIHEAD") || c.nlanes > 1) return;
+    if (getenv("ESAHRNET_NO_MULTIHEAD") || c.nlanes > 1 || c.bf) return;
     auto eligible = [&](const Op& o) {
         if (o.kind != OP_CONV || o.res >= 0 || o.alt != 0 || o.multi >= 0) return false;
         const DevConv& d = c.dconvs[o.dconv];
@@ -669,7 +673,7 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
     size_t top = 0;
     auto bytes_of = [&](const Tensor& t) {
         const size_t wpix = t.tlayout ? (size_t)esa::head_t_xp(sp.lw[t.level]) : (size_t)sp.lw[t.level];
-        size_t b = t.flat ? (size_t)n * t.flat * 4 : (size_t)n * sp.lh[t.level] * wpix * t.Cp * 4;
+        size_t b = t.flat ? (size_t)n * t.flat * 4 : (size_t)n * sp.lh[t.level] * wpix * t.Cp * c.eb();
         return (b + 255) & ~(size_t)255;
     };
     auto alloc = [&](size_t len) {
@@ -830,6 +834,10 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     c->cfg = *cfg;
     c->device = device;
     if (const char* e = getenv("ESAHRNET_UNFUSED")) c->fuse_big = !(e[0] && e[0] != '0');
+    if (cfg->precision == 1) {      // bf16 mode: op-by-op plan on the stream / 1x1 / fuse kernels (the fused stem, block
+        c->bf = true;               // and head kernels are built for the split format only)
+        c->fuse_big = false;
+    }
     if (const char* e = getenv("ESAHRNET_STREAMS")) c->nlanes = atoi(e) > 1 ? 4 : 1;
     if (const char* e = getenv("ESAHRNET_HEAD_V1")) c->head2_enabled = !(e[0] && e[0] != '0');
     if (build_plan(*c)) { delete c; return 1; }
@@ -924,8 +932,13 @@ int esahrnet_commit(esahrnet_handle h) {
                     const int src_ci = d.perm.empty() ? d.c0 + ci : d.perm[ci];
                     w[((size_t)co * cin + ci) * taps + t] = s.w[((size_t)co * s.cin + src_ci) * taps + t];
                 }
-        packed.assign(esa::packed_weight_bytes(d.coutp, d.cinp, s.k), 0);
-        esa::pack_conv_weights(w.data(), s.cout, cin, s.k, d.coutp, d.cinp, packed.data());
+        if (h->bf) {
+            packed.assign(esa::packed_weight_bytes_bf(d.coutp, d.cinp, s.k), 0);
+            esa::pack_conv_weights_bf(w.data(), s.cout, cin, s.k, d.coutp, d.cinp, packed.data());
+        } else {
+            packed.assign(esa::packed_weight_bytes(d.coutp, d.cinp, s.k), 0);
+            esa::pack_conv_weights(w.data(), s.cout, cin, s.k, d.coutp, d.cinp, packed.data());
+        }
         if (upload(packed, &d.w)) return 1;
         std::vector<float> bias(d.coutp, 0.f);
         if (d.use_bias) std::copy(s.b.begin(), s.b.end(), bias.begin());
@@ -950,7 +963,7 @@ int esahrnet_commit(esahrnet_handle h) {
     }
     {   // stem: [cout/8][cin][9][8]
         const ConvSpec& s = h->specs[h->spec_stem];
-        const int coutp = pad32(s.cout);
+        const int coutp = h->padc(s.cout);
         std::vector<float> w((size_t)coutp * s.cin * 9, 0.f), b(coutp, 0.f);
         for (int co = 0; co < s.cout; ++co) {
             b[co] = s.b[co];
@@ -964,7 +977,7 @@ int esahrnet_commit(esahrnet_handle h) {
         const ConvSpec& s = h->specs[h->spec_final];
         const int kt = esa::final_kt(s.cout);
         std::vector<float> w((size_t)s.cin * 9 * kt, 0.f), b(std::max(kt, 32), 0.f);
-        if (esa::final_mfma_supported(s.cout, s.cin - s.cout) && !getenv("ESAHRNET_FINAL_VALU")) {
+        if (!h->bf && esa::final_mfma_supported(s.cout, s.cin - s.cout) && !getenv("ESAHRNET_FINAL_VALU")) {
             packed.assign(esa::final_mfma_bytes(s.cout, s.cin - s.cout), 0);
             esa::pack_final_mfma(s.w.data(), s.cout, s.cin - s.cout, packed.data());
             if (upload(packed, &h->final_wpk)) return 1;
@@ -1081,14 +1094,14 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
             case OP_STEM: {
                 const Tensor& t = h->tensors[o.out];
                 esa::StemParams p{static_cast<const float*>(x_dev), T(o.out), h->stem_w, h->stem_b,
-                                  n, height, width, h->cfg.cin, t.Cp, 1};
+                                  n, height, width, h->cfg.cin, t.Cp, 1, h->bf ? 1 : 0};
                 rc = esa::launch_stem(p, stream);
                 break;
             }
             case OP_STEMRAW: {
                 const Tensor& t = h->tensors[o.out];
                 esa::StemParams p{static_cast<const float*>(x_dev), T(o.out), h->stemraw_w, h->stemraw_b,
-                                  n, height, width, h->cfg.cin, t.Cp, 0};
+                                  n, height, width, h->cfg.cin, t.Cp, 0, 0};
                 rc = esa::launch_stem(p, stream);
                 break;
             }
@@ -1189,7 +1202,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 p.w = static_cast<const uint4*>(d.w); p.bias = d.bias;
                 p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level];
                 p.OH = sp.lh[to.level]; p.OW = sp.lw[to.level];
-                p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu; p.out_f32 = d.out_f32;
+                p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu; p.out_f32 = d.out_f32; p.bf = h->bf ? 1 : 0;
                 rc = esa::launch_conv(p, s.k, s.stride, stream);
                 break;
             }
@@ -1265,7 +1278,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                     p.x[i] = T(o.terms[i]); p.h[i] = sp.lh[ti.level]; p.w[i] = sp.lw[ti.level];
                 }
                 p.y = T(o.out); p.N = n; p.H = sp.lh[to.level]; p.W = sp.lw[to.level]; p.Cp = to.Cp;
-                p.relu = o.relu;
+                p.relu = o.relu; p.bf = h->bf ? 1 : 0;
                 rc = esa::launch_fuse(p, stream);
                 break;
             }
@@ -1275,7 +1288,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 p.h3 = T(o.in); p.x0 = static_cast<const float*>(x_dev); p.out = static_cast<float*>(heat_dev);
                 p.w = h->final_w; p.bias = h->final_b; p.wpk = static_cast<const uint4*>(h->final_wpk);
                 p.N = n; p.H = height; p.W = width; p.h = sp.lh[ti.level]; p.wd = sp.lw[ti.level];
-                p.K = h->cfg.num_keypoints; p.cin = h->cfg.cin; p.Cp = ti.Cp;
+                p.K = h->cfg.num_keypoints; p.cin = h->cfg.cin; p.Cp = ti.Cp; p.bf = h->bf ? 1 : 0;
                 rc = esa::launch_final(p, stream);
                 break;
             }
@@ -1346,7 +1359,7 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
     auto tbytes = [&](int t) {
         const Tensor& x = h->tensors[t];
         const double wpix = x.tlayout ? (double)esa::head_t_xp(lw[x.level]) : (double)lw[x.level];
-        return x.flat ? (double)n * x.flat * 4.0 : (double)n * lh[x.level] * wpix * x.Cp * 4.0;
+        return x.flat ? (double)n * x.flat * 4.0 : (double)n * lh[x.level] * wpix * x.Cp * (double)h->eb();
     };
     switch (o.kind) {
         case OP_STEM: {
@@ -1398,7 +1411,7 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                 const Tensor& ti = h->tensors[o.in];
                 esa::ConvParams q{};
                 q.N = n; q.H = lh[ti.level]; q.W = lw[ti.level]; q.OH = lh[to.level]; q.OW = lw[to.level];
-                q.Cinp = d.cinp; q.Coutp = d.coutp; q.out_f32 = d.out_f32;
+                q.Cinp = d.cinp; q.Coutp = d.coutp; q.out_f32 = d.out_f32; q.bf = h->bf ? 1 : 0;
                 q.res = o.res >= 0 ? reinterpret_cast<const char*>(h) : nullptr;     // only tested against nullptr
                 snprintf(out->kernel, sizeof out->kernel, "%s", esa::conv_kernel_name(q, s.k, s.stride));
             }
@@ -1406,7 +1419,7 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             else snprintf(out->label, sizeof out->label, "%s", s.name.c_str());
             out->flops = 2.0 * n * lh[to.level] * lw[to.level] * s.cout * (d.c1 - d.c0) * s.k * s.k;
             out->bytes = tbytes(o.in) + tbytes(o.out) + (o.res >= 0 ? tbytes(o.res) : 0.0) +
-                         (double)esa::packed_weight_bytes(d.coutp, d.cinp, s.k);
+                         (double)(h->bf ? esa::packed_weight_bytes_bf(d.coutp, d.cinp, s.k) : esa::packed_weight_bytes(d.coutp, d.cinp, s.k));
             break;
         }
         case OP_BLOCK: {
@@ -1558,9 +1571,9 @@ int esahrnet_tap_read(esahrnet_handle h, const char* name, int n, int height, in
     const Tensor* t = find_tap(h, name);
     if (!t) return fail("tap_read: no tensor named '%s'", name);
     if (plan_shape(*h, n, height, width)) return 1;
-    const int rc = esa::launch_sb_to_nchw(static_cast<const char*>(ws_dev) + t->off, n, t->C,
-                                          h->sp.lh[t->level], h->sp.lw[t->level], t->Cp,
-                                          static_cast<float*>(out_dev), static_cast<hipStream_t>(stream));
+    const int rc = (h->bf ? esa::launch_bf_to_nchw : esa::launch_sb_to_nchw)(
+        static_cast<const char*>(ws_dev) + t->off, n, t->C, h->sp.lh[t->level], h->sp.lw[t->level], t->Cp,
+        static_cast<float*>(out_dev), static_cast<hipStream_t>(stream));
     if (rc) return fail("tap_read: %s", hipGetErrorString((hipError_t)rc));
     return 0;
 }
@@ -1569,32 +1582,44 @@ int esahrnet_tap_read(esahrnet_handle h, const char* name, int n, int height, in
 int esahrnet_op_conv(const void* x_dev, int n, int cin, int height, int width, const float* w,
                      const float* b, int cout, int k, int stride, int relu, const void* res_dev,
                      void* y_dev, esahrnet_stream stream_) {
+    return esahrnet_op_conv_ex(x_dev, n, cin, height, width, w, b, cout, k, stride, relu, res_dev, y_dev, 0, stream_);
+}
+
+int esahrnet_op_conv_ex(const void* x_dev, int n, int cin, int height, int width, const float* w,
+                        const float* b, int cout, int k, int stride, int relu, const void* res_dev,
+                        void* y_dev, int precision, esahrnet_stream stream_) {
     if (!x_dev || !w || !b || !y_dev) return fail("op_conv: null argument");
+    if (precision != 0 && precision != 1) return fail("op_conv: precision %d", precision);
+    const bool bf = precision == 1;
+    const int eb = bf ? 2 : 4;
     if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return fail("op_conv: k=%d stride=%d unsupported", k, stride);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int cinp = pad32(cin), coutp = pad32(cout);
+    const int cinp = bf ? pad64(cin) : pad32(cin), coutp = bf ? pad64(cout) : pad32(cout);
     const int oh = stride == 2 ? (height + 1) / 2 : height, ow = stride == 2 ? (width + 1) / 2 : width;
-    std::vector<char> packed(esa::packed_weight_bytes(coutp, cinp, k), 0);
-    esa::pack_conv_weights(w, cout, cin, k, coutp, cinp, packed.data());
+    std::vector<char> packed(bf ? esa::packed_weight_bytes_bf(coutp, cinp, k) : esa::packed_weight_bytes(coutp, cinp, k), 0);
+    if (bf) esa::pack_conv_weights_bf(w, cout, cin, k, coutp, cinp, packed.data());
+    else esa::pack_conv_weights(w, cout, cin, k, coutp, cinp, packed.data());
     std::vector<float> bias(coutp, 0.f);
     std::copy(b, b + cout, bias.begin());
     void *dw = nullptr, *db = nullptr, *xs = nullptr, *ys = nullptr, *rs = nullptr;
     int rc = 0;
     auto cleanup = [&]() { for (void* p : {dw, db, xs, ys, rs}) if (p) (void)hipFree(p); };
     if (upload(packed, &dw) || upload(bias, &db)) { cleanup(); return 1; }
-    const size_t xb = (size_t)n * height * width * cinp * 4, yb = (size_t)n * oh * ow * coutp * 4;
+    const size_t xb = (size_t)n * height * width * cinp * eb, yb = (size_t)n * oh * ow * coutp * eb;
     if (hipMalloc(&xs, xb) != hipSuccess || hipMalloc(&ys, yb) != hipSuccess ||
         (res_dev && hipMalloc(&rs, yb) != hipSuccess)) { cleanup(); return fail("op_conv: hipMalloc failed"); }
-    rc = esa::launch_nchw_to_sb(static_cast<const float*>(x_dev), n, cin, height, width, static_cast<char*>(xs), cinp, stream);
-    if (!rc && res_dev) rc = esa::launch_nchw_to_sb(static_cast<const float*>(res_dev), n, cout, oh, ow, static_cast<char*>(rs), coutp, stream);
+    auto to_internal = bf ? esa::launch_nchw_to_bf : esa::launch_nchw_to_sb;
+    rc = to_internal(static_cast<const float*>(x_dev), n, cin, height, width, static_cast<char*>(xs), cinp, stream);
+    if (!rc && res_dev) rc = to_internal(static_cast<const float*>(res_dev), n, cout, oh, ow, static_cast<char*>(rs), coutp, stream);
     if (!rc) {
         esa::ConvParams p{};
         p.x = static_cast<const char*>(xs); p.y = static_cast<char*>(ys); p.res = static_cast<const char*>(rs);
         p.w = static_cast<const uint4*>(dw); p.bias = static_cast<const float*>(db);
         p.N = n; p.H = height; p.W = width; p.OH = oh; p.OW = ow; p.Cinp = cinp; p.Coutp = coutp; p.relu = relu;
+        p.bf = bf ? 1 : 0;
         rc = esa::launch_conv(p, k, stride, stream);
     }
-    if (!rc) rc = esa::launch_sb_to_nchw(static_cast<const char*>(ys), n, cout, oh, ow, coutp, static_cast<float*>(y_dev), stream);
+    if (!rc) rc = (bf ? esa::launch_bf_to_nchw : esa::launch_sb_to_nchw)(static_cast<const char*>(ys), n, cout, oh, ow, coutp, static_cast<float*>(y_dev), stream);
     hipError_t se = hipStreamSynchronize(stream);
     cleanup();
     if (rc) return fail("op_conv: launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1604,23 +1629,31 @@ int esahrnet_op_conv(const void* x_dev, int n, int cin, int height, int width, c
 
 int esahrnet_op_fuse(const void* const* xs_dev, const int* hs, const int* ws, int nterms, int n, int c,
                      int height, int width, int relu, void* y_dev, esahrnet_stream stream_) {
+    return esahrnet_op_fuse_ex(xs_dev, hs, ws, nterms, n, c, height, width, relu, y_dev, 0, stream_);
+}
+
+int esahrnet_op_fuse_ex(const void* const* xs_dev, const int* hs, const int* ws, int nterms, int n, int c,
+                        int height, int width, int relu, void* y_dev, int precision, esahrnet_stream stream_) {
     if (!xs_dev || !hs || !ws || !y_dev || nterms < 1 || nterms > 4) return fail("op_fuse: bad argument");
+    if (precision != 0 && precision != 1) return fail("op_fuse: precision %d", precision);
+    const bool bf = precision == 1;
+    const int eb = bf ? 2 : 4;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int cp = pad32(c);
+    const int cp = bf ? pad64(c) : pad32(c);
     void* bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     auto cleanup = [&]() { for (void* p : bufs) if (p) (void)hipFree(p); };
     int rc = 0;
     esa::FuseParams p{};
-    p.nterms = nterms; p.N = n; p.H = height; p.W = width; p.Cp = cp; p.relu = relu;
+    p.nterms = nterms; p.N = n; p.H = height; p.W = width; p.Cp = cp; p.relu = relu; p.bf = bf ? 1 : 0;
     for (int i = 0; i < nterms && !rc; ++i) {
-        if (hipMalloc(&bufs[i], (size_t)n * hs[i] * ws[i] * cp * 4) != hipSuccess) { cleanup(); return fail("op_fuse: hipMalloc failed"); }
-        rc = esa::launch_nchw_to_sb(static_cast<const float*>(xs_dev[i]), n, c, hs[i], ws[i], static_cast<char*>(bufs[i]), cp, stream);
+        if (hipMalloc(&bufs[i], (size_t)n * hs[i] * ws[i] * cp * eb) != hipSuccess) { cleanup(); return fail("op_fuse: hipMalloc failed"); }
+        rc = (bf ? esa::launch_nchw_to_bf : esa::launch_nchw_to_sb)(static_cast<const float*>(xs_dev[i]), n, c, hs[i], ws[i], static_cast<char*>(bufs[i]), cp, stream);
         p.x[i] = static_cast<const char*>(bufs[i]); p.h[i] = hs[i]; p.w[i] = ws[i];
     }
-    if (!rc && hipMalloc(&bufs[4], (size_t)n * height * width * cp * 4) != hipSuccess) { cleanup(); return fail("op_fuse: hipMalloc failed"); }
+    if (!rc && hipMalloc(&bufs[4], (size_t)n * height * width * cp * eb) != hipSuccess) { cleanup(); return fail("op_fuse: hipMalloc failed"); }
     p.y = static_cast<char*>(bufs[4]);
     if (!rc) rc = esa::launch_fuse(p, stream);
-    if (!rc) rc = esa::launch_sb_to_nchw(p.y, n, c, height, width, cp, static_cast<float*>(y_dev), stream);
+    if (!rc) rc = (bf ? esa::launch_bf_to_nchw : esa::launch_sb_to_nchw)(p.y, n, c, height, width, cp, static_cast<float*>(y_dev), stream);
     hipError_t se = hipStreamSynchronize(stream);
     cleanup();
     if (rc) return fail("op_fuse: launch failed: %s", hipGetErrorString((hipError_t)rc));

@@ -120,3 +120,33 @@ __device__ __forceinline__ void join8(uint4 hi, uint4 lo, float v[8]) {
     join4(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y), v);
     join4(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), v + 4);
 }
+
+// ---- "BF" = single bf16 NHWC (esahrnet_cfg.precision == 1, BASELINE configs[3]) ---------------------------------
+// A tensor [N][H][W][Cp] of plain bf16, Cp = channels padded to a multiple of 64 with exact zeros: 2 bytes per
+// channel, half of SB.  A pixel's channels come in 64-channel blocks of 128 bytes = 8 chunks of 16 bytes (8
+// consecutive channels each), natural order.  The convolution kernels stage one 128-byte block per pixel exactly as
+// they stage one 32-channel SB chunk (same loads, same 8 LDS planes); what used to be the (hi, lo) plane pair of
+// k-group g now holds the two MFMA K-steps of the block — chunk g (channels 8g..8g+7) and chunk 4+g (channels
+// 32+8g..) — so a block costs 2 MFMAs per tap and row where the split format costs 3 for half as many channels.
+__host__ __device__ __forceinline__ constexpr int bf_plane_of_chunk(int jst) { return 2 * (jst & 3) + (jst >> 2); }
+
+// 4 floats -> 4 bf16 (8 bytes), round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint2 pack4_bf16(const float v[4]) {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    return make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2)),
+                      __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2)));
+}
+__device__ __forceinline__ void unpack4_bf16(uint2 c, float v[4]) {
+    v[0] = __uint_as_float(c.x << 16);
+    v[1] = __uint_as_float(c.x & 0xffff0000u);
+    v[2] = __uint_as_float(c.y << 16);
+    v[3] = __uint_as_float(c.y & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8_bf16(const float v[8]) {
+    const uint2 a = pack4_bf16(v), b = pack4_bf16(v + 4);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void unpack8_bf16(uint4 c, float v[8]) {
+    unpack4_bf16(make_uint2(c.x, c.y), v);
+    unpack4_bf16(make_uint2(c.z, c.w), v + 4);
+}

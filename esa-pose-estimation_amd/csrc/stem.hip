@@ -56,6 +56,10 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, long long total
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = relu1(acc[i]);
     }
+    if (p.bf) {
+        *reinterpret_cast<uint4*>(p.y + (((size_t)(n * p.H + y) * p.W + x) * p.cout) * 2 + c8 * 16) = pack8_bf16(acc);
+        return;
+    }
     uint4 hi, lo;
     split8(acc, hi, lo);
     char* o = p.y + (((size_t)(n * p.H + y) * p.W + x) * p.cout) * 4 + c8 * 32;

@@ -176,6 +176,14 @@ int esahrnet_op_conv(const void* x_dev, int n, int cin, int height, int width,
 int esahrnet_op_fuse(const void* const* xs_dev, const int* hs, const int* ws, int nterms,
                      int n, int c, int height, int width, int relu, void* y_dev,
                      esahrnet_stream stream);
+/* The same two operators in the arithmetic of esahrnet_cfg.precision (0: split-bf16, 1: single bf16): inputs are
+ * converted to the internal format, the kernel of that mode runs, the result is converted back to f32. */
+int esahrnet_op_conv_ex(const void* x_dev, int n, int cin, int height, int width,
+                        const float* w, const float* b, int cout, int k, int stride, int relu,
+                        const void* res_dev, void* y_dev, int precision, esahrnet_stream stream);
+int esahrnet_op_fuse_ex(const void* const* xs_dev, const int* hs, const int* ws, int nterms,
+                        int n, int c, int height, int width, int relu, void* y_dev, int precision,
+                        esahrnet_stream stream);
 
 /* ---- test hooks ------------------------------------------------------------------------------------ */
 /* Launch state is kept per DEVICE (dynamic-LDS limits raised per kernel and device, CU counts), never in
