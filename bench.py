@@ -14,7 +14,18 @@ One JSON line on stdout (rank 0), carrying also
   "roofline":     dominant kernel (3x3 stride-1 split-bf16 MFMA convolution) — algorithmic FLOPs
                   per launch / HIP-event duration per launch, against the bf16x3 MFMA peak;
   "cpu_baseline": the CPU oracle (torch-CPU restatement of the reference forward + numpy
-                  post-processing) timed on this box's host cores on a bounded sample.
+                  post-processing) timed on this box's host cores on a bounded sample: batch 1 on all
+                  cores (the headline row), batch 1 on one thread and batch 32 on all cores (BASELINE.md §2);
+  "extras" (N = 1 only, all measured AFTER the timed region, none of them is `value`):
+      latency_b1_us        one crop, graph-replayed and eager (the reference calls the net per image, val.py:112)
+      sustained            the same step over >= 2000 back-to-back replays (clocks settle under load)
+      config3_w48_384_bf16 BASELINE.json configs[3]: HRNet-W48 384x384 batch 64 in the single-pass bf16 mode,
+                           with its own roofline block (MFMA and HBM fractions of its dominant kernel)
+      seg_hrnet3           the CBAM network val.py:380 instantiates, batch 32 256x256, with its own roofline block.
+
+Other workloads as the headline of an explicit run (never what the driver runs):
+    python bench.py --workload w48-bf16        (configs[3])
+    python bench.py --variant seg_hrnet3
 """
 import argparse
 import json
@@ -29,12 +40,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# gfx950 dense peaks (/opt/skills/guides/MI355X_MICROARCH.md): bf16 MFMA ~2.5 PFLOP/s, f32 157.3 TFLOP/s.
+# gfx950 dense peaks (/opt/skills/guides/MI355X_MICROARCH.md): bf16 MFMA ~2.5 PFLOP/s, f32 157.3 TFLOP/s, HBM3E 8 TB/s.
 # The split-bf16 scheme issues 3 bf16 MFMA FLOPs per algorithmic FLOP, so the ceiling for
-# ALGORITHMIC FLOP/s of the convolution kernels is 2500/3 TFLOP/s.
+# ALGORITHMIC FLOP/s of the convolution kernels is 2500/3 TFLOP/s; the single-pass bf16 mode prices against 2500.
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 3.0
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0
 
 
 def parse():
@@ -42,12 +54,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step")
-    ap.add_argument("--hw", type=int, default=256)
-    ap.add_argument("--variant", default="seg_hrnet2", choices=["seg_hrnet2", "seg_hrnet"])
+    ap.add_argument("--batch", type=int, default=None, help="crops per GPU per step (default: 32; 64 for w48-bf16)")
+    ap.add_argument("--hw", type=int, default=None)
+    ap.add_argument("--workload", default="w32", choices=["w32", "w48-bf16", "w48"],
+                    help="w32: BASELINE configs[1] (headline); w48-bf16: configs[3]; w48: the same net in split-bf16")
+    ap.add_argument("--variant", default="seg_hrnet2", choices=["seg_hrnet2", "seg_hrnet", "seg_hrnet3"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline time budget")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the headline CPU-baseline row")
+    ap.add_argument("--sustained-steps", type=int, default=2000)
     ap.add_argument("--profile-steps", type=int, default=3, help="instrumented forwards for the roofline leg")
     return ap.parse_args()
 
@@ -82,13 +98,11 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(sd, cfg, variant, hw, budget_s):
-    """Oracle (kind 'port') on the host cores: batch-1 forwards + numpy post-processing."""
+def _time_oracle(sd, cfg, hw, batch, threads, budget_s, min_iters=3, max_iters=200):
     from esa_pose_estimation_amd import synth
     from oracle import hrnet_ref, keypoints_ref
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    x = synth.make_crops(1, cfg["cin"], hw, hw, seed=0)
+    torch.set_num_threads(threads)
+    x = synth.make_crops(batch, cfg["cin"], hw, hw, seed=0)
 
     def one():
         with torch.no_grad():
@@ -96,20 +110,153 @@ def cpu_baseline(sd, cfg, variant, hw, budget_s):
         keypoints_ref.heatmaps_to_keypoints(y.numpy())
 
     t_w = time.perf_counter()
-    for _ in range(2):
+    one()                                               # warm-up (bounded: a pathological host stops here)
+    if time.perf_counter() - t_w < budget_s / 4:
         one()
-        if time.perf_counter() - t_w > budget_s:       # pathological host: keep the run bounded
-            break
     times = []
     t_end = time.perf_counter() + budget_s
-    while time.perf_counter() < t_end and len(times) < 200:
+    while (time.perf_counter() < t_end or len(times) < min_iters) and len(times) < max_iters:
         t0 = time.perf_counter()
         one()
         times.append(time.perf_counter() - t0)
+        if len(times) >= min_iters and time.perf_counter() - t_w > 3 * budget_s:
+            break
     med = float(np.median(times))
-    return {"value": round(1.0 / med, 3), "unit": "crops/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} batch-1 forwards of {variant} W32 {hw}x{hw} + numpy arg-max/refine "
-                      f"(oracle/hrnet_ref.py, torch {torch.__version__} CPU, median {med * 1e3:.1f} ms/crop)"}
+    return batch / med, med, len(times)
+
+
+def cpu_baseline(sd, cfg, variant, hw, budget_s):
+    """Oracle (kind 'port') on the host cores.  Headline row: batch-1 forwards + numpy post-processing on all
+    cores; BASELINE.md §2 also asks for 1 thread and for batch 32 — shorter budgets, same protocol."""
+    cores = host_cores()
+    v, med, n = _time_oracle(sd, cfg, hw, 1, cores, budget_s)
+    out = {"value": round(v, 3), "unit": "crops/s", "cores": cores, "kind": "port",
+           "sample": f"{n} batch-1 forwards of {variant} W32 {hw}x{hw} + numpy arg-max/refine "
+                     f"(oracle/hrnet_ref.py, torch {torch.__version__} CPU, median {med * 1e3:.1f} ms/crop)"}
+    rows = []
+    for batch, threads, budget in ((1, 1, budget_s / 2), (32, cores, budget_s / 2)):
+        try:
+            v, med, n = _time_oracle(sd, cfg, hw, batch, threads, budget, min_iters=2)
+            rows.append({"batch": batch, "threads": threads, "value": round(v, 3), "unit": "crops/s",
+                         "median_ms_per_forward": round(med * 1e3, 1), "forwards": n})
+        except Exception as e:                          # noqa: BLE001 - a baseline row must not sink the bench line
+            rows.append({"batch": batch, "threads": threads, "error": str(e)})
+    out["rows"] = rows
+    torch.set_num_threads(cores)
+    return out
+
+
+def build_net(variant, widths, precision, dev, seed=0):
+    from esa_pose_estimation_amd import config, synth
+    mod = getattr(__import__("esa_pose_estimation_amd." + variant), variant)
+    net = mod.get_seg_model(config.make_config(widths=widths), precision=precision)
+    sd = synth.make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=seed)
+    net.load_state_dict(sd, strict=True)
+    return net.to(dev).eval(), sd
+
+
+def capture(local_step, enabled=True):
+    """HIP-graph capture of one local step (torch.cuda.graph); (None, None) when disabled or refused."""
+    if not enabled:
+        return None, None
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            local_step()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = local_step()
+        return graph, out
+    except Exception as e:                              # noqa: BLE001
+        print(f"[bench] HIP graph capture failed ({e}); running eager", file=sys.stderr)
+        return None, None
+
+
+def roofline_leg(net, x, profile_steps, precision):
+    """Per-launch HIP-event durations of instrumented forwards -> (roofline block, per-kernel breakdown)."""
+    per = None
+    for _ in range(max(1, profile_steps)):
+        _, ops = net.forward_timed(x)
+        if per is None:
+            per = [dict(o, ms=0.0) for o in ops]
+        for a, o in zip(per, ops):
+            a["ms"] += o["ms"] / max(1, profile_steps)
+    groups = {}
+    for o in per:
+        gk = groups.setdefault(o["kernel"], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        gk["launches"] += 1
+        gk["ms"] += o["ms"]
+        gk["flops"] += o["flops"]
+        gk["bytes"] += o["bytes"]
+    # dominant kernel = the matrix-core kernel with the largest share of the step
+    dominant = max((k for k, v in groups.items() if v["flops"] > 0), key=lambda k: groups[k]["ms"])
+    d = groups[dominant]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    gbps = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dominant)
+        except Exception:
+            traffic = None
+    bf16 = precision == "bf16"
+    peak = PEAK_BF16_TFLOPS if bf16 else PEAK_BF16X3_TFLOPS
+    roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+            "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+            "frac_of_f32_peak": round(ach / PEAK_F32_TFLOPS, 4),
+            "algorithmic_gbps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / PEAK_HBM_GBPS, 4),
+            "peak_note": ("single-pass bf16: one MFMA FLOP per algorithmic FLOP -> ceiling 2500 TFLOP/s; layer-by-layer bf16 "
+                          "is HBM-bound on the wide-resolution branches, hence both fractions (compulsory bytes / 8 TB/s)")
+            if bf16 else "split-bf16: 3 bf16 MFMA FLOPs per algorithmic FLOP -> ceiling 2500/3 TFLOP/s"}
+    tot_ms = sum(v["ms"] for v in groups.values())
+    breakdown = {k: {"launches": v["launches"], "ms": round(v["ms"], 4), "share": round(v["ms"] / tot_ms, 4),
+                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
+                     "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
+                 for k, v in groups.items()}
+    roof["whole_step_event_ms"] = round(tot_ms, 4)
+    roof["launches_per_forward"] = len(per)
+    return roof, breakdown
+
+
+def side_workload(tag, variant, widths, precision, batch, hw, dev, steps, warmup, profile_steps):
+    """A second workload measured with the same protocol (graph replay, K steps between syncs) for `extras`."""
+    from esa_pose_estimation_amd import inference, parallel, synth
+    net, _ = build_net(variant, widths, precision, dev)
+    x = synth.make_crops(batch, net._cin, hw, hw, seed=2000).to(dev)
+
+    def local_step():
+        return inference.heatmaps_to_keypoints(net(x))
+
+    with torch.no_grad():
+        local_step()
+        torch.cuda.synchronize()
+        graph, out = capture(local_step)
+
+        def step():
+            if graph is not None:
+                graph.replay()
+                return out
+            return local_step()
+        elapsed, kp = parallel.timed_steps(step, steps, warmup, sync=torch.cuda.synchronize)
+        assert bool(torch.isfinite(kp).all())
+        roof, breakdown = roofline_leg(net, x, profile_steps, precision)
+    flops_crop = net.flops_per_crop(hw, hw)
+    value = batch * steps / elapsed
+    res = {"workload": tag, "value": round(value, 1), "unit": "crops/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "batch": batch, "steps": steps, "hip_graph": graph is not None, "launches": roof["launches_per_forward"],
+           "dtype": "bf16 (single-pass bf16 MFMA, f32 accumulate, f32 bias epilogue)" if precision == "bf16"
+           else "bf16x3 (split-bf16 MFMA, f32 accumulate)",
+           "algorithmic_gflop_per_crop": round(flops_crop / 1e9, 3),
+           "whole_net_algorithmic_tflops": round(value * flops_crop / 1e12, 2),
+           "roofline": roof, "kernel_breakdown": breakdown}
+    del net, x, graph, out
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -129,136 +276,122 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    from esa_pose_estimation_amd import config, inference, parallel, synth
-    import esa_pose_estimation_amd as pkg
-    mod = getattr(__import__("esa_pose_estimation_amd." + args.variant), args.variant)
-    net = mod.get_seg_model(config.make_config())
-    sd = synth.make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=0)
-    net.load_state_dict(sd, strict=True)
-    net = net.to(dev).eval()
+    from esa_pose_estimation_amd import inference, parallel, synth
+    w48 = args.workload.startswith("w48")
+    widths = (48, 96, 192, 384) if w48 else (32, 64, 128, 256)
+    precision = "bf16" if args.workload == "w48-bf16" else "bf16x3"
+    B = args.batch or (64 if w48 else 32)
+    hw = args.hw or (384 if w48 else 256)
+    net, sd = build_net(args.variant, widths, precision, dev)
     cin, K = net._cin, net.num_keypoints
-    B, hw = args.batch, args.hw
     n_total = B * world
     # every rank generates only its own shard of the global synthetic batch
     x = synth.make_crops(B, cin, hw, hw, seed=1000 + rank).to(dev)
 
     def local_step():
-        heat = net(x)
-        return inference.heatmaps_to_keypoints(heat)
+        return inference.heatmaps_to_keypoints(net(x))
 
     with torch.no_grad():
-        kp = local_step()                      # folds + uploads weights, allocates workspace
+        local_step()                           # folds + uploads weights, allocates workspace
         torch.cuda.synchronize()
-        graph = None
-        if not args.no_graph:
-            try:
-                s = torch.cuda.Stream()
-                s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):
-                    local_step()
-                torch.cuda.current_stream().wait_stream(s)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    kp = local_step()
-            except Exception as e:             # noqa: BLE001
-                print(f"[bench] HIP graph capture failed ({e}); running eager", file=sys.stderr)
-                graph = None
+        graph, kp = capture(local_step, not args.no_graph)
 
-        def step():
+        def replay_or_eager():
             if graph is not None:
                 graph.replay()
-                out = kp
-            else:
-                out = local_step()
-            if world > 1:
-                return parallel.gather_keypoints(out, n_total)
-            return out
+                return kp
+            return local_step()
 
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            allkp = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        step = parallel.make_sharded_step(replay_or_eager, n_total) if world > 1 else replay_or_eager
+        elapsed, allkp = parallel.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, device=dev)
         assert allkp.shape == (n_total, K, 3) and bool(torch.isfinite(allkp).all())
 
-        # ---- roofline leg (rank 0): per-launch HIP-event durations of instrumented forwards ----
-        roof = None
-        breakdown = None
+        roof = breakdown = None
         if rank == 0:
-            per = None
-            for _ in range(max(1, args.profile_steps)):
-                _, ops = net.forward_timed(x)
-                if per is None:
-                    per = [dict(o, ms=0.0) for o in ops]
-                for a, o in zip(per, ops):
-                    a["ms"] += o["ms"] / max(1, args.profile_steps)
-            groups = {}
-            for o in per:
-                gk = groups.setdefault(o["kernel"], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-                gk["launches"] += 1
-                gk["ms"] += o["ms"]
-                gk["flops"] += o["flops"]
-                gk["bytes"] += o["bytes"]
-            # dominant kernel = the matrix-core kernel with the largest share of the step
-            dominant = max((k for k, v in groups.items() if v["flops"] > 0), key=lambda k: groups[k]["ms"])
-            d = groups[dominant]
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            roof, breakdown = roofline_leg(net, x, args.profile_steps, precision)
+
+        extras = None
+        if rank == 0 and world == 1 and not args.no_extras and args.workload == "w32" and args.variant == "seg_hrnet2":
+            extras = {}
+            # ---- batch-1 latency (val.py:112 calls the net once per image) --------------------------------------
+            x1 = x[:1].clone()
+
+            def step1():
+                return inference.heatmaps_to_keypoints(net(x1))
+            step1()
+            torch.cuda.synchronize()
+            g1, _ = capture(step1)
+            lat = {}
+            for name, fn in (("graph", (lambda: g1.replay()) if g1 is not None else None), ("eager", step1)):
+                if fn is None:
+                    continue
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    fn()
+                    torch.cuda.synchronize()                # latency: the caller waits for every crop
+                lat[name] = round((time.perf_counter() - t0) / 200 * 1e6, 1)
+            host = []
+            for _ in range(10):                             # few calls from an idle queue: no back-pressure from the GPU
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    step1()
+                host.append((time.perf_counter() - t0) / 4)
+            lat["eager_host_enqueue"] = round(float(np.median(host)) * 1e6, 1)
+            torch.cuda.synchronize()
+            lat["note"] = ("one W32 256x256 crop, forward + keypoints, wall time per call including the wait for the "
+                           "result; eager_host_enqueue = host time of one eager call (checks + ~90 launches)")
+            extras["latency_b1_us"] = lat
+            del g1
+            # ---- sustained throughput -----------------------------------------------------------------------------
+            if args.sustained_steps > 0:
+                el, _ = parallel.timed_steps(replay_or_eager, args.sustained_steps, 10, sync=torch.cuda.synchronize)
+                extras["sustained"] = {"value": round(B * args.sustained_steps / el, 1), "unit": "crops/s",
+                                       "steps": args.sustained_steps,
+                                       "ms_per_step": round(el / args.sustained_steps * 1e3, 4),
+                                       "seconds": round(el, 2)}
+            # ---- BASELINE configs[3] and the production network ----------------------------------------------------
+            for key, a in (("config3_w48_384_bf16", ("HRNet-W48 384x384 batch 64, bf16 storage / f32 accumulate (BASELINE configs[3])",
+                                                     "seg_hrnet2", (48, 96, 192, 384), "bf16", 64, 384)),
+                           ("seg_hrnet3", ("seg_hrnet3 (CBAM, val.py:380) W32 256x256 batch 32, 30 keypoints",
+                                           "seg_hrnet3", (32, 64, 128, 256), "bf16x3", 32, 256))):
                 try:
-                    traffic = json.load(open(tpath)).get(dominant)
-                except Exception:
-                    traffic = None
-            roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2),
-                    "peak": round(PEAK_BF16X3_TFLOPS, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16X3_TFLOPS, 4), "traffic": traffic,
-                    "launches_per_step": d["launches"],
-                    "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
-                    "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
-                    "frac_of_f32_peak": round(ach / PEAK_F32_TFLOPS, 4),
-                    "peak_note": "split-bf16: 3 bf16 MFMA FLOPs per algorithmic FLOP -> ceiling 2500/3 TFLOP/s"}
-            tot_ms = sum(v["ms"] for v in groups.values())
-            breakdown = {k: {"launches": v["launches"], "ms": round(v["ms"], 4),
-                             "share": round(v["ms"] / tot_ms, 4),
-                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
-                             "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
-                         for k, v in groups.items()}
+                    extras[key] = side_workload(*a, dev, steps=max(5, min(args.steps, 20)), warmup=3,
+                                                profile_steps=max(1, min(args.profile_steps, 2)))
+                except Exception as e:                  # noqa: BLE001 - an extra must not sink the headline
+                    extras[key] = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import hrnet_ref
-        cpu = cpu_baseline(sd, hrnet_ref.default_cfg(cin, K), args.variant, hw, args.cpu_seconds)
+        variant_id = 1 if args.variant == "seg_hrnet3" else 0
+        cpu = cpu_baseline(sd, hrnet_ref.default_cfg(cin, K, widths=widths, variant=variant_id), args.variant, hw,
+                           args.cpu_seconds)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total * args.steps / elapsed
         flops_crop = net.flops_per_crop(hw, hw)
+        wname = "W48" if w48 else "W32"
+        cfg_idx = 3 if args.workload == "w48-bf16" else (1 if world == 1 else 2)
         line = {
-            "metric": "HRNet-W32 256x256 crops/sec (heatmaps + fused argmax/refine keypoints)",
+            "metric": f"HRNet-{wname} {hw}x{hw} crops/sec (heatmaps + fused argmax/refine keypoints)",
             "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (split-bf16 MFMA, f32 accumulate; f32 VALU stem/head)",
+            "dtype": "bf16 (single-pass bf16 MFMA, f32 accumulate, f32 bias epilogue; f32 VALU stem conv1 / output layer)"
+            if precision == "bf16" else "bf16x3 (split-bf16 MFMA, f32 accumulate; f32 VALU stem/head)",
             "data": "synthetic",
-            "config": {"workload": f"{args.variant} HRNet-W32 {hw}x{hw}, batch {B}/GPU, {K} keypoints, "
-                                   f"fp32 NCHW in -> heatmaps -> keypoints (BASELINE configs[{1 if world == 1 else 2}])",
+            "config": {"workload": f"{args.variant} HRNet-{wname} {hw}x{hw}, batch {B}/GPU, {K} keypoints, "
+                                   f"fp32 NCHW in -> heatmaps -> keypoints (BASELINE configs[{cfg_idx}])",
                        "global_batch": n_total, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "hip_graph": graph is not None,
+                       "hip_graph": graph is not None, "launches_per_forward": roof["launches_per_forward"] if roof else None,
                        "algorithmic_gflop_per_crop": round(flops_crop / 1e9, 3),
                        "whole_net_algorithmic_tflops": round(value * flops_crop / 1e12 / world, 2)},
-            "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+            "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown, "extras": extras,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

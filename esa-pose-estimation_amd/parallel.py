@@ -46,10 +46,13 @@ def gather_keypoints(local_kp: torch.Tensor, n_total: int, group=None) -> torch.
     return torch.cat(parts, 0)
 
 
-def sharded_keypoints(net, crops: torch.Tensor, group=None) -> torch.Tensor:
+def sharded_keypoints(net, crops: torch.Tensor, group=None, keypoints_fn=None) -> torch.Tensor:
     """Every rank holds (or can index) the full batch `crops` [N,Cin,H,W]; each runs its slice
-    through `net` + the fused keypoint kernel and all ranks return the full [N,K,3]."""
-    from .inference import heatmaps_to_keypoints
+    through `net` + the fused keypoint kernel and all ranks return the full [N,K,3].
+    `keypoints_fn` (default: inference.heatmaps_to_keypoints, GPU only) maps the rank's heat-maps to [n,K,3]."""
+    if keypoints_fn is None:
+        from .inference import heatmaps_to_keypoints as keypoints_fn
+    heatmaps_to_keypoints = keypoints_fn
     n_total = crops.shape[0]
     if dist.is_available() and dist.is_initialized():
         lo, hi = shard_bounds(n_total, dist.get_world_size(group), dist.get_rank(group))
@@ -61,3 +64,39 @@ def sharded_keypoints(net, crops: torch.Tensor, group=None) -> torch.Tensor:
     else:
         kp = crops.new_zeros((0, k, 3))
     return gather_keypoints(kp, n_total, group)
+
+
+# ---- the measurement protocol of bench.py, importable so that the N > 1 branch runs under gloo on the CPU too ----
+def make_sharded_step(local_step, n_total: int, group=None):
+    """step() = this rank's shard through `local_step` (eager forward + keypoints, or a HIP-graph replay that
+    returns its static output tensor), then the path's one exchange: the keypoint all-gather."""
+    def step():
+        return gather_keypoints(local_step(), n_total, group)
+    return step
+
+
+def timed_steps(step, steps: int, warmup: int, sync=None, device=None, group=None):
+    """W untimed steps, then exactly K steps bracketed by (device sync + barrier) on both sides; returns
+    (elapsed seconds = MAX over ranks, output of the last step).  `sync`: callable draining the device
+    (torch.cuda.synchronize on a GPU, nothing on the CPU)."""
+    import time
+    sync = sync or (lambda: None)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    if multi:
+        dist.barrier(group)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    if multi:
+        dist.barrier(group)
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        elapsed = float(t.item())
+    return elapsed, out
