@@ -100,3 +100,45 @@ def make_gaussian_heatmaps(n: int, k: int, h: int, w: int, seed: int = 0, sigma:
                  (ys[None, None] - cy[..., None, None]) ** 2) / (2 * sigma * sigma))
     g = g + noise * normal("hm_noise", seed, (n, k, h, w)).astype(np.float64)
     return torch.from_numpy(g.astype(np.float32))
+
+
+# ---- synthetic SPEED-shaped evaluation set (BASELINE.json configs[4]; SURVEY.md §8f NEXT-2 "12 000-image set") ----
+ESA_CAMERA = np.array([[3003.41297, 0.0, 960.0], [0.0, 3003.41297, 600.0], [0.0, 0.0, 1.0]])   # lib/utils/base_utils.py:250-252
+
+
+def make_scene(n: int, k: int, seed: int = 0, img_w: int = 1920, img_h: int = 1200):
+    """n images of one rigid k-keypoint model under known random poses, as the pipeline meets them:
+    -> dict(kp3d [k,3], q [n,4] = [w,x,y,z], t [n,3], uv [n,k,2] image-pixel projections with the ESA camera,
+            bboxes [n][4] = (x, y, x2, y2) detector-style boxes around the projections).
+    Poses are drawn so that the whole model stays inside the 1920x1200 frame (SPEED's spacecraft always is)."""
+    kp3d = uniform("scene_kp3d", seed, (k, 3), -0.6, 0.6).astype(np.float64)
+    rv = normal("scene_rv", seed, (n, 4)).astype(np.float64)
+    q = rv / np.linalg.norm(rv, axis=1, keepdims=True)
+    tz = uniform("scene_tz", seed, (n,), 4.0, 14.0).astype(np.float64)
+    fx, cx, cy = ESA_CAMERA[0, 0], ESA_CAMERA[0, 2], ESA_CAMERA[1, 2]
+    # image-plane centre anywhere that keeps a 1.1 m radius model inside the frame
+    r_px = fx * 1.1 / tz
+    u0 = cx + (uniform("scene_u", seed, (n,), -1.0, 1.0) * np.maximum(img_w / 2 - r_px - 8, 0)).astype(np.float64)
+    v0 = cy + (uniform("scene_v", seed, (n,), -1.0, 1.0) * np.maximum(img_h / 2 - r_px - 8, 0)).astype(np.float64)
+    t = np.stack([(u0 - cx) * tz / fx, (v0 - cy) * tz / fx, tz], 1)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], 1),
+                  np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], 1),
+                  np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)
+    pc = np.einsum("nij,kj->nki", R, kp3d) + t[:, None, :]
+    uv = np.stack([fx * pc[..., 0] / pc[..., 2] + cx, fx * pc[..., 1] / pc[..., 2] + cy], 2)
+    lo, hi = uv.min(1), uv.max(1)
+    pad = 0.08 * (hi - lo).max(1, keepdims=True) + 4.0            # a detector box is a little loose
+    bboxes = np.concatenate([np.floor(lo - pad), np.ceil(hi + pad)], 1).astype(int)
+    bboxes[:, [0, 2]] = np.clip(bboxes[:, [0, 2]], 0, img_w)
+    bboxes[:, [1, 3]] = np.clip(bboxes[:, [1, 3]], 0, img_h)
+    return dict(kp3d=kp3d, q=q, t=t, uv=uv, bboxes=bboxes.tolist())
+
+
+def render_heatmaps(centers: torch.Tensor, size: int, sigma: float = 2.0) -> torch.Tensor:
+    """What a trained network emits for keypoints at `centers` [N,K,2] (crop pixels, x then y): sigma-2 Gaussian
+    blobs (data_load4.py:54-58 labels) -> f32 [N,K,size,size] on centers' device."""
+    ax = torch.arange(size, dtype=torch.float32, device=centers.device)
+    dx = (ax[None, None, :] - centers[..., 0:1]) ** 2            # [N,K,S]
+    dy = (ax[None, None, :] - centers[..., 1:2]) ** 2
+    return torch.exp(-(dy[..., :, None] + dx[..., None, :]) / (2.0 * sigma * sigma))
