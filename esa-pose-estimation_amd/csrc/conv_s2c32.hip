@@ -93,7 +93,12 @@ __device__ __forceinline__ int div_magic(int b, int d, uint32_t m) {
 // channels per pixel — the same loads, planes and reads as a 32-channel split chunk — whose plane pair (2g, 2g+1) holds
 // the block's two MFMA K-steps instead of (hi, lo); the weight registers wh / wl hold the K-step 0 / 1 fragments; a
 // tap of a row is 2 MFMAs for 64 channels instead of 3 for 32; accumulators leave as 8 bytes of bf16 per lane.
-template <int S, int TH, int MW, bool MH = false, bool BF = false>
+// DB: two tile buffers in LDS and ONE barrier per step.  The tile of step s+1 (in registers since step s-1) is written
+// into the other buffer right behind the barrier that opens step s, while the first operand reads of step s are in
+// flight, and the loads of step s+2 are issued behind it; the barrier that opens step s+1 then publishes that tile
+// and retires the reads of step s at once.  (Single-buffered: barrier, write, barrier, and the LDS-read pipe starts
+// cold behind the second one.)
+template <int S, int TH, int MW, bool MH = false, bool BF = false, bool DB = false>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, StreamGeo geo) {
     using S2C = ConvCfg<3, S, TH, 2>;
     constexpr int RG = 4 / MW;                  // row groups
@@ -175,18 +180,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
         }                                                                                         \
     }
 
-    const char* xrd = xs + S2C::plane_off(2 * g) + ((rg * NT * S) * S2C::IW + (lane & 15) * S) * 16;
+    const char* xrd0 = xs + S2C::plane_off(2 * g) + ((rg * NT * S) * S2C::IW + (lane & 15) * S) * 16;
+    auto write_tile = [&](int b_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < S2C::XITER; ++it)
+            if (!(S2_ABL & 2) && q0 + it * 32 < S2C::NPIX)
+                *reinterpret_cast<u32x4*>(xwr + (DB ? b_ * S2C::XBYTES : 0) + it * 512) = xr[it];
+    };
 
     decode(item);
     prefetch(s_n, 0);
-    S2_LOAD_W(s_ct, 0, 0)
-    S2_LOAD_W(s_ct, 0, 1)
-    S2_LOAD_W(s_ct, 0, 2)
     int n = s_n, oy0 = s_oy0, ox0 = s_ox0, ct = s_ct;      // the item being computed
-    f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + (ct * MW + mw) * 16 + g * 4);
     int c = 0;
     bool first = true;
     f32x4 acc[NT];
+    // DB look-ahead: step1 = the step behind the current one (its tile is in xr), coordinates of its item in s1_*
+    int buf = 0, item1 = item, c1 = 0, s1_n = s_n, s1_oy0 = s_oy0, s1_ox0 = s_ox0, s1_ct = s_ct;
+    bool ok1 = false;
+    if (DB) {
+        write_tile(0);                                           // tile of step 0; published by the first barrier
+        ok1 = nchunks > 1 || item + G < geo.nitems;
+        if (nchunks > 1) {
+            c1 = 1;
+        } else if (ok1) {
+            item1 = item + G;
+            decode(item1);
+        }
+        s1_n = s_n; s1_oy0 = s_oy0; s1_ox0 = s_ox0; s1_ct = s_ct;
+        prefetch(s_n, c1);
+    }
+    // the first weights go out BEHIND the tile loads, as in every later step: the counted vmcnt that hipcc puts in front
+    // of the tile commit at the loop head is the minimum over the loop entry and the back edge, and with nothing younger
+    // than the tile on the entry path it would drain the weight loads of every step
+    __builtin_amdgcn_sched_barrier(0);          // (hipcc would hoist the weight loads above the tile loads)
+    S2_LOAD_W(ct, 0, 0)
+    S2_LOAD_W(ct, 0, 1)
+    S2_LOAD_W(ct, 0, 2)
+    f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + (ct * MW + mw) * 16 + g * 4);
 #ifdef S2_TRACE
     int tstep = 0;
     // traced: the first 32 workgroups and the first 32 of the second half (the second workgroup of a CU)
@@ -205,29 +235,73 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
     while (true) {
         TR(0)
         const bool last_chunk = c + 1 == nchunks;
-        const bool more = !last_chunk || item + G < geo.nitems;          // is there a step s+1?
-        if (!first && !(S2_ABL & 16)) __syncthreads();            // previous step's MFMAs are done reading the planes
-        first = false;
-        TR(1)
-#pragma unroll
-        for (int it = 0; it < S2C::XITER; ++it)
-            if (!(S2_ABL & 2) && q0 + it * 32 < S2C::NPIX) *reinterpret_cast<u32x4*>(xwr + it * 512) = xr[it];
-        TR(2)
-        if (!(S2_ABL & 16)) __syncthreads();
-        TR(3)
-        // step s+1: next chunk of this item, or chunk 0 of the workgroup's next item (the last step of the
-        // stream prefetches its own tile again: harmless, keeps the loop free of branches around loads)
-        int nct = ct, nch = c + 1;
-        if (last_chunk) {
-            nch = 0;
-            if (more) {
-                decode(item + G);
-                nct = s_ct;
-            }
+        const bool more = DB ? ok1 : (!last_chunk || item + G < geo.nitems);          // is there a step s+1?
+        const char* xrd = xrd0 + (DB ? buf * S2C::XBYTES : 0);
+        bf16x8 fh[RD + 1], fo[RD + 1];
+#define S2_READ(IDX)                                                                              \
+        {                                                                                         \
+            const int off_ = (((IDX) % ROWS) * S2C::IW + (IDX) / ROWS) * 16;                      \
+            if (!(S2_ABL & 64)) {                                                                 \
+                fh[(IDX) % (RD + 1)] = *reinterpret_cast<const bf16x8*>(xrd + off_);              \
+                fo[(IDX) % (RD + 1)] = *reinterpret_cast<const bf16x8*>(xrd + off_ + S2C::LO_OFF); \
+            } else if ((IDX) < RD + 1) {                                                          \
+                fh[(IDX) % (RD + 1)] = wh[(IDX) % 9];                                             \
+                fo[(IDX) % (RD + 1)] = wl[(IDX) % 9];                                             \
+            }                                                                                     \
         }
-        prefetch(s_n, nch);
-        TR(4)
-        const bool reload = !(S2_ABL & 4) && more && (nchunks > 1 || nct != ct);
+        int nct = ct, nch = c + 1;
+        int item2 = item1, c2 = c1;
+        bool ok2 = false;
+        if (DB) {
+            if (!(S2_ABL & 16)) __syncthreads();      // tile of this step published, reads of the previous step retired
+            TR(3)
+#pragma unroll
+            for (int r = 0; r < RD; ++r) S2_READ(r)    // start the operand pipe before the staging work
+            __builtin_amdgcn_sched_barrier(0);
+            if (ok1) write_tile(buf ^ 1);              // tile of step s+1 -> the buffer step s-1 was read from
+            // step s+2 = the step behind step1: next chunk of its item, or chunk 0 of the workgroup's next item (beyond
+            // the end of the stream the last tile is fetched again: harmless, keeps the loop free of branches around loads)
+            nct = s1_ct; nch = c1;
+            ok2 = ok1;
+            if (c1 + 1 < nchunks) {
+                c2 = c1 + 1;
+            } else {
+                c2 = 0;
+                item2 = item1 + G;
+                ok2 = ok1 && item2 < geo.nitems;
+                if (ok2) decode(item2);
+            }
+            prefetch(s_n, c2);
+            TR(4)
+        } else {
+            if (!first && !(S2_ABL & 16)) __syncthreads();            // previous step's MFMAs are done reading the planes
+            first = false;
+            TR(1)
+            write_tile(0);
+            TR(2)
+            if (!(S2_ABL & 16)) __syncthreads();
+            TR(3)
+            // step s+1: next chunk of this item, or chunk 0 of the workgroup's next item (the last step of the
+            // stream prefetches its own tile again: harmless, keeps the loop free of branches around loads)
+            if (last_chunk) {
+                nch = 0;
+                if (more) {
+                    decode(item + G);
+                    nct = s_ct;
+                }
+            }
+            prefetch(s_n, nch);
+            TR(4)
+        }
+        constexpr bool S2_STATIC_LOADS = DB;
+        // DB variant: loads are issued UNCONDITIONALLY (the weight thirds of the next step even when they are the ones already held,
+        // the residual rows even when the layer has none: an out-of-range offset costs an issue slot, no traffic): with a
+        // load behind a run-time condition hipcc cannot count what is in flight and falls back to vmcnt(0) — observed:
+        // the tile commit at the start of every step waited for the weight third issued just before the barrier, the
+        // residual fold for the third issued just before it.  (Costs redundant weight loads on single-chunk layers; measured
+        // on MI355X, batch 32: with two workgroups per CU neither this nor the second barrier moves a layer — the partner
+        // wave fills every stall — so the variant is used where a launch has at most one workgroup per CU.)
+        const bool reload = S2_STATIC_LOADS ? !(S2_ABL & 4) : (!(S2_ABL & 4) && more && (nchunks > 1 || nct != ct));
         int co = (ct * MW + mw) * 16 + g * 4;                   // cout of the lane's accumulator quad ...
         if (MH) {                                               // ... inside its head's tensor
             const int cb = (ct * MW + mw) * 16;                 // per wave: a 64-cout slice may span two heads
@@ -258,7 +332,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
 #pragma unroll
             for (int t = 0; t < NH; ++t) {
                 const int tt = half * NH + t;
-                const uint32_t ro_ = (tt < NT && tt < nrows) ? o0 + (uint32_t)(tt * orow) : OOB;
+                const uint32_t ro_ = (tt < NT && tt < nrows && (!S2_STATIC_LOADS || do_res)) ? o0 + (uint32_t)(tt * orow) : OOB;
                 if (BF) {
                     const auto r2 = __builtin_amdgcn_raw_buffer_load_b64(rr, (int)ro_, yso, 0);
                     rc[t] = u32x4{r2[0], r2[1], 0u, 0u};
@@ -304,19 +378,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
             // row landed in this row's columns 12..15 whenever the scheduler put it right behind the store).
             __builtin_amdgcn_raw_buffer_store_b128(cv, ry, (int)(so_ + (uint32_t)yso), 0, 0);
         };
-        if (do_res) res_load(0);
-        bf16x8 fh[RD + 1], fo[RD + 1];
-#define S2_READ(IDX)                                                                              \
-        {                                                                                         \
-            const int off_ = (((IDX) % ROWS) * S2C::IW + (IDX) / ROWS) * 16;                      \
-            if (!(S2_ABL & 64)) {                                                                 \
-                fh[(IDX) % (RD + 1)] = *reinterpret_cast<const bf16x8*>(xrd + off_);              \
-                fo[(IDX) % (RD + 1)] = *reinterpret_cast<const bf16x8*>(xrd + off_ + S2C::LO_OFF); \
-            } else if ((IDX) < RD + 1) {                                                          \
-                fh[(IDX) % (RD + 1)] = wh[(IDX) % 9];                                             \
-                fo[(IDX) % (RD + 1)] = wl[(IDX) % 9];                                             \
-            }                                                                                     \
-        }
+        if (S2_STATIC_LOADS || do_res) res_load(0);
         // one kx phase.  The third phase of a last chunk is straight-line code of its own: the epilogue of output
         // row t (ReLU, split, chunk swap, store: ~20 VALU instructions) is emitted one input row after the row's
         // last MFMA and rides in the issue shadow of the next row's MFMAs instead of running after the phase with
@@ -357,8 +419,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
                     if (t * S + 3 > ROWS - 1) epilogue_row(t, res_c);      // rows finished by the final input rows
             }
         };
+        if (!DB) {
 #pragma unroll
-        for (int r = 0; r < RD; ++r) S2_READ(r)
+            for (int r = 0; r < RD; ++r) S2_READ(r)
+        }
         phase(std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
         if (reload) S2_LOAD_W(nct, nch, 0)          // this third is free: refill it for step s+1
         TR(5)
@@ -372,8 +436,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[t][i] += r_[i];
             }
-            if (NT >= 2) res_load(1);
+            if (!S2_STATIC_LOADS && NT >= 2) res_load(1);
         }
+        if (S2_STATIC_LOADS && NT >= 2) res_load(1);
         TR(6)
         if (!last_chunk) phase(std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{});
         else if (do_res) phase(std::integral_constant<int, 2>{}, std::true_type{}, std::true_type{});
@@ -402,10 +467,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
             if (!more) break;
             if (nct != ct) bv = *reinterpret_cast<const f32x4*>(p.bias + (nct * MW + mw) * 16 + g * 4);
             item += G;
-            n = s_n; oy0 = s_oy0; ox0 = s_ox0; ct = s_ct;
+            if (DB) { n = s1_n; oy0 = s1_oy0; ox0 = s1_ox0; ct = s1_ct; }
+            else { n = s_n; oy0 = s_oy0; ox0 = s_ox0; ct = s_ct; }
             c = 0;
         } else {
             ++c;
+        }
+        if (DB) {                                   // step1 <- step2
+            item1 = item2; c1 = c2; ok1 = ok2;
+            s1_n = s_n; s1_oy0 = s_oy0; s1_ox0 = s_ox0; s1_ct = s_ct;
+            buf ^= 1;
         }
 #ifdef S2_TRACE
         ++tstep;
@@ -432,9 +503,21 @@ int images_per_launch(const ConvParams& p) {
     return (int)std::min<long long>(p.N, g_launch_limit.load(std::memory_order_relaxed) / std::max(per, 1LL));
 }
 
+#ifndef S2_DB
+#define S2_DB 1          // 1: stride-1 launches with at most one workgroup per CU run the double-buffered variant
+#endif
+template <int S, int TH, int MW, bool MH, bool BF, bool DB>
+int launch_s2c32_k(const ConvParams& p, const StreamGeo& geo, int grid, hipStream_t stream) {
+    using S2C = ConvCfg<3, S, TH, 2>;
+    constexpr int LDS = (DB ? 2 : 1) * S2C::XBYTES;
+    auto kern = conv_s2c32_kernel<S, TH, MW, MH, BF, DB>;
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS)) return e_;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), LDS, stream, p, geo);
+    return (int)hipGetLastError();
+}
+
 template <int S, int TH, int MW, bool MH = false, bool BF = false>
 int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
-    using S2C = ConvCfg<3, S, TH, 2>;
     constexpr int EB = BF ? 2 : 4;
     const int nmax = images_per_launch(p);
     if (nmax < 1) return (int)hipErrorInvalidValue;
@@ -451,8 +534,6 @@ int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
         }
         return 0;
     }
-    auto kern = conv_s2c32_kernel<S, TH, MW, MH, BF>;
-    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), S2C::XBYTES)) return e_;
     StreamGeo geo;
     geo.tiles_x = (p.OW + TW - 1) / TW;
     geo.tiles_y = (p.OH + TH - 1) / TH;
@@ -463,11 +544,15 @@ int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
     geo.m_ct = magic_of(geo.ctiles);
     geo.m_tx = magic_of(geo.tiles_x);
     geo.m_ty = magic_of(geo.tiles_y);
-    const int slots = 2 * device_cus();
+    const int cus = device_cus(), slots = 2 * cus;
     int grid = (int)(nitems < slots ? nitems : slots);
     if (grid > geo.ctiles) grid -= grid % geo.ctiles;   // grid stride keeps the cout slice of a workgroup constant
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), S2C::XBYTES, stream, p, geo);
-    return (int)hipGetLastError();
+    // Both variants run the same MFMAs in the same order on every accumulator: a crop's result does not depend on which
+    // one a batch size selects.
+    if constexpr (S2_DB && S == 1 && !MH) {
+        if (nitems <= cus) return launch_s2c32_k<S, TH, MW, MH, BF, true>(p, geo, grid, stream);
+    }
+    return launch_s2c32_k<S, TH, MW, MH, BF, false>(p, geo, grid, stream);
 }
 
 }  // namespace
