@@ -582,7 +582,7 @@ const char* conv_kernel_name(const ConvParams& p, int k, int stride) {
         }
     }
     switch (choose_conv(p, k, stride)) {
-        case C_STREAM_S1: return p.Coutp % 64 == 0 ? "conv_s2c32_kernel<1, 8, 4, false>" : "conv_s2c32_kernel<1, 8, 2, false>";
+        case C_STREAM_S1: return use_th16(p) ? "conv_s2c32_kernel<1, 16, 4, false>" : p.Coutp % 64 == 0 ? "conv_s2c32_kernel<1, 8, 4, false>" : "conv_s2c32_kernel<1, 8, 2, false>";
         case C_TILE_S1_8: return ring ? "conv_mfma_ring_kernel<1, 8, 2>" : persist ? "conv_mfma_kernel<3, 1, 8, 2, true>" : "conv_mfma_kernel<3, 1, 8, 2, false>";
         case C_TILE_S1_16: return ring ? "conv_mfma_ring_kernel<1, 16, 2>" : persist ? "conv_mfma_kernel<3, 1, 16, 2, true>" : "conv_mfma_kernel<3, 1, 16, 2, false>";
         case C_STREAM_S2: return p.Coutp % 64 == 0 ? "conv_s2c32_kernel<2, 4, 4, false>" : "conv_s2c32_kernel<2, 4, 2, false>";

@@ -98,8 +98,9 @@ __device__ __forceinline__ int div_magic(int b, int d, uint32_t m) {
 // flight, and the loads of step s+2 are issued behind it; the barrier that opens step s+1 then publishes that tile
 // and retires the reads of step s at once.  (Single-buffered: barrier, write, barrier, and the LDS-read pipe starts
 // cold behind the second one.)
-template <int S, int TH, int MW, bool MH = false, bool BF = false, bool DB = false>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, StreamGeo geo) {
+// OCC: workgroups per CU the register budget is cut for (2: 256 VGPRs per wave; 1: 512 — the 16-row tile).
+template <int S, int TH, int MW, bool MH = false, bool BF = false, bool DB = false, int OCC = 2>
+__global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p, StreamGeo geo) {
     using S2C = ConvCfg<3, S, TH, 2>;
     constexpr int RG = 4 / MW;                  // row groups
     constexpr int NT = TH / RG;                 // output rows per wave
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_kernel(ConvParams p, S
 #ifndef S2_RD84
 #define S2_RD84 1
 #endif
-    constexpr int RD = (S == 1 && MW == 2) ? S2_RD : (S == 1 && MW == 4) ? S2_RD84 : 1;   // as many rows as the register budget allows
+    constexpr int RD = OCC == 1 ? 2 : (S == 1 && MW == 2) ? S2_RD : (S == 1 && MW == 4) ? S2_RD84 : 1;   // as many rows as the register budget allows
     constexpr bool INPHASE = S2_INPHASE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
@@ -506,11 +507,11 @@ int images_per_launch(const ConvParams& p) {
 #ifndef S2_DB
 #define S2_DB 1          // 1: stride-1 launches with at most one workgroup per CU run the double-buffered variant
 #endif
-template <int S, int TH, int MW, bool MH, bool BF, bool DB>
+template <int S, int TH, int MW, bool MH, bool BF, bool DB, int OCC = 2>
 int launch_s2c32_k(const ConvParams& p, const StreamGeo& geo, int grid, hipStream_t stream) {
     using S2C = ConvCfg<3, S, TH, 2>;
     constexpr int LDS = (DB ? 2 : 1) * S2C::XBYTES;
-    auto kern = conv_s2c32_kernel<S, TH, MW, MH, BF, DB>;
+    auto kern = conv_s2c32_kernel<S, TH, MW, MH, BF, DB, OCC>;
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS)) return e_;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), LDS, stream, p, geo);
     return (int)hipGetLastError();
@@ -544,15 +545,19 @@ int launch_s2c32_t(const ConvParams& p, hipStream_t stream) {
     geo.m_ct = magic_of(geo.ctiles);
     geo.m_tx = magic_of(geo.tiles_x);
     geo.m_ty = magic_of(geo.tiles_y);
-    const int cus = device_cus(), slots = 2 * cus;
+    const int cus = device_cus(), slots = (TH == 16 ? 1 : 2) * cus;
     int grid = (int)(nitems < slots ? nitems : slots);
     if (grid > geo.ctiles) grid -= grid % geo.ctiles;   // grid stride keeps the cout slice of a workgroup constant
-    // Both variants run the same MFMAs in the same order on every accumulator: a crop's result does not depend on which
+    // All variants run the same MFMAs in the same order on every accumulator: a crop's result does not depend on which
     // one a batch size selects.
-    if constexpr (S2_DB && S == 1 && !MH) {
-        if (nitems <= cus) return launch_s2c32_k<S, TH, MW, MH, BF, true>(p, geo, grid, stream);
+    if constexpr (TH == 16) {
+        return launch_s2c32_k<S, TH, MW, MH, BF, true, 1>(p, geo, grid, stream);
+    } else {
+        if constexpr (S2_DB && S == 1 && !MH) {
+            if (nitems <= cus) return launch_s2c32_k<S, TH, MW, MH, BF, true>(p, geo, grid, stream);
+        }
+        return launch_s2c32_k<S, TH, MW, MH, BF, false>(p, geo, grid, stream);
     }
-    return launch_s2c32_k<S, TH, MW, MH, BF, false>(p, geo, grid, stream);
 }
 
 }  // namespace
@@ -598,9 +603,26 @@ int launch_conv_s2c32_multi(const ConvParams& p, hipStream_t stream) {
 // the same scheme for stride 1: 64 couts x 8 rows per workgroup (wave = cout tile) where the layer has a
 // multiple of 64 couts, else 32 couts x 8 rows (wave = cout tile x 4 rows; the 16-row tile of earlier builds sat at
 // 256 VGPRs and was 4-14 % slower)
+#ifndef S2_TH16
+#define S2_TH16 0
+#endif
+// Experiment kept for the record (-DS2_TH16=1): ONE workgroup per CU with the full register file on a 16-row tile
+// (64 couts x 16 rows x 16 columns, 432 MFMAs per wave and barrier, read-ahead 2).  Measured on MI355X, batch 32:
+// 31-33 us against 25-26 us on the 64-channel layers, 27 against 22-23 on the 128-channel ones — a lone wave per SIMD
+// loses more to its own stalls than the longer step wins back — and the residual is folded at another point of the
+// accumulation, so results are not bit-identical to the 8-row tile.  Not used.
+bool use_th16(const ConvParams& p) {
+    if (!S2_TH16 || p.bf || p.Coutp % 64 != 0 || p.OH < 16) return false;
+    const long long items16 = (long long)p.N * ((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 64);
+    return items16 >= device_cus();
+}
+
 int launch_conv_s1w(const ConvParams& p, hipStream_t stream) {
     if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
     if (p.bf) return launch_s2c32_t<1, 8, 4, false, true>(p, stream);
+#if S2_TH16
+    if (use_th16(p)) return launch_s2c32_t<1, 16, 4>(p, stream);
+#endif
     if (p.Coutp % 64 == 0) return launch_s2c32_t<1, 8, 4>(p, stream);
     return launch_s2c32_t<1, 8, 2>(p, stream);
 }

@@ -41,6 +41,7 @@ const char* conv_kernel_name(const ConvParams& p, int k, int stride);
 bool conv_s2c32_supported(const ConvParams& p);
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream);
 int launch_conv_s1w(const ConvParams& p, hipStream_t stream);
+bool use_th16(const ConvParams& p);               // stride-1 stream kernel: 16-row tile, one workgroup per CU (conv_s2c32.hip)
 void set_stream_launch_limit(long long bytes);     // test hook, see conv_s2c32.hip images_per_launch
 // 1x1, Cinp in {64..384}: all input channels of 16 pixels in registers, weights streamed through LDS (conv1x1.hip)
 bool conv1x1_supported(const ConvParams& p);
