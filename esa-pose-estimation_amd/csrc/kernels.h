@@ -138,6 +138,12 @@ int launch_head(const HeadParams& p, hipStream_t stream);
 bool head_fused_supported(int H, int W, const int th[3], const int tw[3], int C0p, int K);
 size_t head_w3_bytes(int K, int Ctp);
 void pack_head_w3(const float* w, int K, int Ct, int Ctp, void* dst);
+// bf16 mode (head_fused_bf.hip): x0, t[b] and y are BF tensors; w0 = pack_conv_weights_bf(k = 1) of the branch-0 slice
+// [Ctp/16][C0p/64][K-step][64], w3 = pack_head_w3_bf [M3][Ctp/32][64] (one bf16 fragment per chunk)
+int launch_head_bf(const HeadParams& p, hipStream_t stream);
+bool head_fused_bf_supported(int H, int W, const int th[3], const int tw[3], int C0p, int K);
+size_t head_w3_bf_bytes(int K, int Ctp);
+void pack_head_w3_bf(const float* w, int K, int Ct, int Ctp, void* dst);
 
 // ---- second-generation fused head: bilinear up-sampling on the matrix cores (head_t.hip, head_fused2.hip)
 constexpr int HT_PAD = 1;       // T layout: stored column = x + HT_PAD

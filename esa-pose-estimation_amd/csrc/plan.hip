@@ -72,7 +72,7 @@ struct DevConv {                // one MFMA convolution launch (a ConvSpec or a 
     float* bias = nullptr;      // device, f32 [coutp]
 };
 
-enum OpKind { OP_STEM, OP_STEMF, OP_CONV, OP_BLOCK, OP_FUSE, OP_HEAD, OP_HEADT, OP_HEAD2, OP_FINAL,
+enum OpKind { OP_STEM, OP_STEMF, OP_CONV, OP_BLOCK, OP_FUSE, OP_HEAD, OP_HEADT, OP_HEAD2, OP_FINAL, OP_HEADBF,
               // seg_hrnet3 (CBAM) variant only:
               OP_STEMRAW, OP_POOL, OP_MLP, OP_MAPS, OP_APPLY, OP_RESAMPLE, OP_ZERO, OP_TONCHW };
 
@@ -591,18 +591,54 @@ int build_plan_ops(esahrnet_ctx& c) {
             c.head2_op = B.push(q);
         }
     } else {
-        std::vector<int> hterms;
+        // bf16 mode: the slices t_1..t_3 are shared by two alternatives, chosen per input shape (plan_shape):
+        // alt 2 = head_fused_bf.hip (W0, interpolation, ReLU, last_layer[3] in one kernel) where its source-region
+        // geometry holds, alt 1 = slice 0 + fuse + 1x1 (the 720-channel tensors materialised) otherwise
+        const bool bf_head = c.bf && ys.size() == 4 && (c.padc(pre[0]) == 64 || c.padc(pre[0]) == 128) &&
+                             !getenv("ESAHRNET_BF_UNFUSED_HEAD");
+        std::vector<int> hterms(ys.size(), -1);
         int off = 0;
-        for (size_t b = 0; b < ys.size(); ++b) {
+        std::vector<int> offs;
+        for (size_t b = 0; b < ys.size(); ++b) { offs.push_back(off); off += pre[b]; }
+        for (size_t b = bf_head ? 1 : 0; b < ys.size(); ++b) {
             // the slice runs at branch b's own resolution: fix the output level of the slice conv
             const int save = c.specs[l0].level;
             c.specs[l0].level = 1 + (int)b;
-            hterms.push_back(B.conv(l0, ys[b], -1, false, "", off, off + pre[b], b == 0));
+            hterms[b] = B.conv(l0, ys[b], -1, false, "", offs[b], offs[b] + pre[b], b == 0);
             c.specs[l0].level = save;
-            off += pre[b];
         }
-        const int h0 = B.fuse(hterms, tot, 1, true, "head0");
-        h3 = B.conv(l3, h0, -1, true, "head3");
+        int h3b = -1;
+        if (bf_head) {
+            const int first_alt1 = (int)c.ops.size();
+            const int save = c.specs[l0].level;
+            hterms[0] = B.conv(l0, ys[0], -1, false, "", 0, pre[0], true);
+            c.specs[l0].level = save;
+            c.spec_l0 = l0; c.spec_l3 = l3; c.head_c0 = pre[0];
+            Op q; q.kind = OP_HEADBF; q.in = ys[0]; q.nterms = 3; q.alt = 2;
+            for (int b = 1; b < 4; ++b) q.terms[b - 1] = hterms[b];
+            q.out = B.tensor(K, 1, "head3_fused");
+            c.tensors[q.out].Cp = K <= 16 ? 16 : 32;      // read only by the output-layer kernel
+            c.tensors[q.out].alt = 2;
+            h3b = q.out;
+            // alternative 1 first (its ops and tensors carry alt = 1), then the fused op
+            const int h0 = B.fuse(hterms, tot, 1, true, "head0");
+            h3 = B.conv(l3, h0, -1, true, "head3");
+            for (int k = first_alt1; k < (int)c.ops.size(); ++k) {
+                c.ops[k].alt = 1;
+                if (c.ops[k].out >= 0) c.tensors[c.ops[k].out].alt = 1;
+            }
+            c.head2_op = B.push(q);
+        } else {
+            const int h0 = B.fuse(hterms, tot, 1, true, "head0");
+            h3 = B.conv(l3, h0, -1, true, "head3");
+        }
+        if (h3b >= 0) {
+            Op o; o.kind = OP_FINAL; o.in = h3b; o.alt = 2;
+            B.push(o);
+            Op o1; o1.kind = OP_FINAL; o1.in = h3; o1.alt = 1;
+            B.push(o1);
+            return 0;
+        }
     }
     {
         Op o; o.kind = OP_FINAL; o.in = h3;
@@ -638,6 +674,10 @@ bool head2_for_shape(const esahrnet_ctx& c, const std::vector<int>& lh, const st
         th[i] = lh[lv]; tw[i] = lw[lv];
     }
     const Tensor& t0 = c.tensors[o.in];
+    if (o.kind == OP_HEADBF) {
+        if (ulo) *ulo = false;
+        return esa::head_fused_bf_supported(lh[t0.level], lw[t0.level], th, tw, t0.Cp, c.cfg.num_keypoints);
+    }
     return esa::head_fused2_supported(lh[t0.level], lw[t0.level], th, tw, t0.Cp, c.tensors[o.terms[0]].Cp,
                                       c.cfg.num_keypoints, ulo);
 }
@@ -1006,16 +1046,25 @@ int esahrnet_commit(esahrnet_handle h) {
     if (h->spec_l0 >= 0) {   // fused head: W0 slice (standard pack), W3 (permuted-K pack), biases
         const ConvSpec& s0 = h->specs[h->spec_l0];
         const ConvSpec& s3 = h->specs[h->spec_l3];
-        const int ct = s0.cout, ctp = pad32(ct), c0 = h->head_c0, c0p = pad32(c0), c3p = pad32(s3.cout);
+        const int ct = s0.cout, ctp = h->padc(ct), c0 = h->head_c0, c0p = h->padc(c0), c3p = pad32(s3.cout);
         std::vector<float> w((size_t)ct * c0);
         for (int co = 0; co < ct; ++co)
             for (int ci = 0; ci < c0; ++ci) w[(size_t)co * c0 + ci] = s0.w[(size_t)co * s0.cin + ci];
-        packed.assign(esa::packed_weight_bytes(ctp, c0p, 1), 0);
-        esa::pack_conv_weights(w.data(), ct, c0, 1, ctp, c0p, packed.data());
-        if (upload(packed, &h->head_w0)) return 1;
-        packed.assign(esa::head_w3_bytes(s3.cout, ctp), 0);
-        esa::pack_head_w3(s3.w.data(), s3.cout, ct, ctp, packed.data());
-        if (upload(packed, &h->head_w3)) return 1;
+        if (h->bf) {
+            packed.assign(esa::packed_weight_bytes_bf(ctp, c0p, 1), 0);
+            esa::pack_conv_weights_bf(w.data(), ct, c0, 1, ctp, c0p, packed.data());
+            if (upload(packed, &h->head_w0)) return 1;
+            packed.assign(esa::head_w3_bf_bytes(s3.cout, ctp), 0);
+            esa::pack_head_w3_bf(s3.w.data(), s3.cout, ct, ctp, packed.data());
+            if (upload(packed, &h->head_w3)) return 1;
+        } else {
+            packed.assign(esa::packed_weight_bytes(ctp, c0p, 1), 0);
+            esa::pack_conv_weights(w.data(), ct, c0, 1, ctp, c0p, packed.data());
+            if (upload(packed, &h->head_w0)) return 1;
+            packed.assign(esa::head_w3_bytes(s3.cout, ctp), 0);
+            esa::pack_head_w3(s3.w.data(), s3.cout, ct, ctp, packed.data());
+            if (upload(packed, &h->head_w3)) return 1;
+        }
         std::vector<float> b0(ctp, 0.f), b3(c3p, 0.f);
         std::copy(s0.b.begin(), s0.b.end(), b0.begin());
         std::copy(s3.b.begin(), s3.b.end(), b3.begin());
@@ -1238,6 +1287,23 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 rc = esa::launch_head(p, stream);
                 break;
             }
+            case OP_HEADBF: {
+                const Tensor& ti = h->tensors[o.in];
+                const Tensor& to = h->tensors[o.out];
+                esa::HeadParams p{};
+                p.x0 = T(o.in); p.y = T(o.out);
+                p.w0 = static_cast<const uint4*>(h->head_w0); p.w3 = static_cast<const uint4*>(h->head_w3);
+                p.bias0 = h->head_b0; p.bias3 = h->head_b3;
+                p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level];
+                for (int i = 0; i < 3; ++i) {
+                    const Tensor& tt = h->tensors[o.terms[i]];
+                    p.t[i] = T(o.terms[i]); p.th[i] = sp.lh[tt.level]; p.tw[i] = sp.lw[tt.level];
+                    p.Ctp = tt.Cp;
+                }
+                p.C0p = ti.Cp; p.C3p = to.Cp; p.K = h->cfg.num_keypoints;
+                rc = esa::launch_head_bf(p, stream);
+                break;
+            }
             case OP_HEADT: {
                 const Tensor& ti = h->tensors[o.in];
                 const Tensor& to = h->tensors[o.out];
@@ -1443,6 +1509,17 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             for (int i = 0; i < 3; ++i) out->bytes += tbytes(o.terms[i]);
             break;
         }
+        case OP_HEADBF: {
+            const ConvSpec& s0 = h->specs[h->spec_l0];
+            const ConvSpec& s3 = h->specs[h->spec_l3];
+            const Tensor& to = h->tensors[o.out];
+            snprintf(out->kernel, sizeof out->kernel, "head_fused_bf");
+            snprintf(out->label, sizeof out->label, "last_layer.0[:, 0:%d] + up + last_layer.3", h->head_c0);
+            out->flops = 2.0 * n * lh[to.level] * lw[to.level] * ((double)s0.cout * h->head_c0 + (double)s3.cout * s3.cin);
+            out->bytes = tbytes(o.in) + tbytes(o.out);
+            for (int i = 0; i < 3; ++i) out->bytes += tbytes(o.terms[i]);
+            break;
+        }
         case OP_HEADT: {
             const DevConv& d = h->dconvs[o.dconv];
             const ConvSpec& s = h->specs[d.spec];
@@ -1571,6 +1648,8 @@ int esahrnet_tap_read(esahrnet_handle h, const char* name, int n, int height, in
     const Tensor* t = find_tap(h, name);
     if (!t) return fail("tap_read: no tensor named '%s'", name);
     if (plan_shape(*h, n, height, width)) return 1;
+    if (t->alt != 0 && t->alt != (h->sp.head2 ? 2 : 1))
+        return fail("tap_read: '%s' belongs to the head alternative that does not run at this shape", name);
     const int rc = (h->bf ? esa::launch_bf_to_nchw : esa::launch_sb_to_nchw)(
         static_cast<const char*>(ws_dev) + t->off, n, t->C, h->sp.lh[t->level], h->sp.lw[t->level], t->Cp,
         static_cast<float*>(out_dev), static_cast<hipStream_t>(stream));

@@ -405,7 +405,10 @@ class _Runtime:
             c, th, tw = C.c_int(), C.c_int(), C.c_int()
             _lib.check(self.lib.esahrnet_tap_shape(h, name, hh, ww, C.byref(c), C.byref(th), C.byref(tw)))
             t = torch.empty((n, c.value, th.value, tw.value), dtype=torch.float32, device=dev)
-            _lib.check(self.lib.esahrnet_tap_read(h, name, n, hh, ww, ws_ptr, t.data_ptr(), C.c_void_p(stream)))
+            if self.lib.esahrnet_tap_read(h, name, n, hh, ww, ws_ptr, t.data_ptr(), C.c_void_p(stream)) != 0:
+                if b"head alternative" in self.lib.esahrnet_last_error():
+                    continue                # tensor of the head variant this shape does not run
+                _lib.check(1)
             out[name.decode()] = t
         _lib.check(self.lib.esahrnet_set_debug_keep(h, 0))
         return out

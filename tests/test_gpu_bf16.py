@@ -166,9 +166,14 @@ def test_bf16_intermediates_match_emulation(env):
     with torch.no_grad():
         env["emu"].forward(sd, env["hrnet_ref"].default_cfg(1, 11), x, taps_emu)
         taps = net.taps(x.cuda())
-    assert {"stem1", "stem2", "layer1", "stage2.0", "stage4.3", "head0", "head3"} <= set(taps)
+    assert {"stem1", "stem2", "layer1", "stage2.0", "stage4.3"} <= set(taps)
+    assert ("head0" in taps and "head3" in taps) != ("head3_fused" in taps)     # exactly one head alternative ran
     worst = {}
     for name, ref in taps_emu.items():
+        if name == "head3" and "head3_fused" in taps:
+            name = "head3_fused"            # head_fused_bf.hip: the 720-channel head0 never exists
+        elif name not in taps:
+            continue
         got = taps[name].cpu()
         assert got.shape == ref.shape, (name, got.shape, ref.shape)
         assert torch.equal(qb(got), got), name                        # stored tensors are bf16 data
@@ -177,6 +182,18 @@ def test_bf16_intermediates_match_emulation(env):
         # a flipped rounding is one bf16 ulp of the value: allow a few ulps, relative to the tensor's scale
         assert float(err.max()) <= 2.0 ** -6 * float(ref.abs().max()), (name, float(err.max()))
     print("bf16 taps vs emulation, worst abs diff:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+def test_bf16_unfused_head_alternative(env, monkeypatch):
+    """ESAHRNET_BF_UNFUSED_HEAD=1: slice 0 + fuse + 1x1 instead of head_fused_bf (the alternative odd geometries take)."""
+    monkeypatch.setenv("ESAHRNET_BF_UNFUSED_HEAD", "1")
+    net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 3)
+    x = env["synth"].make_crops(1, 1, 128, 128, seed=3)
+    with torch.no_grad():
+        emu = env["emu"].forward(sd, env["hrnet_ref"].default_cfg(1, 11), x)
+        y, ops = net.forward_timed(x.cuda())
+    assert "head_fused_bf" not in {o["kernel"] for o in ops}
+    assert (y.cpu() - emu).abs().max().item() <= TOL_EMU and (y.cpu() - emu).abs().mean().item() <= TOL_EMU_MEAN
 
 
 @pytest.mark.parametrize("hw", [(48, 80), (16, 16), (18, 34), (104, 72)])
@@ -229,5 +246,6 @@ def test_bf16_plan_reports_its_kernels(env):
     kernels = {o["kernel"] for o in ops}
     print(sorted(kernels))
     assert "conv_s2c32_kernel<1, 8, 4, false, true>" in kernels and "conv1x1_kernel<bf16>" in kernels
-    assert not any(k.startswith(("bblock32", "head_fused", "stem_fused", "conv_mfma")) for k in kernels)
+    assert "head_fused_bf" in kernels
+    assert not any(k.startswith(("bblock32", "head_fused2", "head_t", "stem_fused", "conv_mfma")) for k in kernels)
     assert all(o["bytes"] > 0 for o in ops)
