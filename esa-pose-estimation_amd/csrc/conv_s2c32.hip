@@ -108,7 +108,9 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p,
 #ifndef S2_RD84
 #define S2_RD84 1
 #endif
-    constexpr int RD = OCC == 1 ? 2 : (S == 1 && MW == 2) ? S2_RD : (S == 1 && MW == 4) ? S2_RD84 : 1;   // as many rows as the register budget allows
+    // LDS read-ahead in input rows: as many as the register budget allows (the bf16 64-cout variant spills 8 VGPRs at 1
+    // and its big layers are HBM-bound: 0)
+    constexpr int RD = OCC == 1 ? 2 : (S == 1 && MW == 2) ? S2_RD : (S == 1 && MW == 4) ? (BF ? 0 : S2_RD84) : 1;
     constexpr bool INPHASE = S2_INPHASE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
@@ -325,40 +327,57 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p,
         // residual (last chunk only): the first half of the wave's rows is loaded at the start of the step and folded
         // into the accumulators after the second phase; the second half is loaded then and folded in by the row's
         // epilogue.  16-byte chunks (sb.h).
+        // Residual (last chunk only): the first half of the wave's rows is loaded at the start of the step and folded into
+        // the accumulators after the second phase; the second half is loaded then and folded in while the last phase runs.
+        //   split format: 16-byte chunks, halves swapped into accumulator quads (sb.h), f32 adds on the VALU;
+        //   bf16 format:  through the matrix pipe, acc += I·r — one more MFMA per output row whose A operand is a 16x32
+        //                 selector (idA) and whose B operand is the residual AS IT LIES IN MEMORY: lane (pixel, g < 2)
+        //                 loads the 16-byte chunk of 8 channels 8g.. of the wave's cout tile, lanes g >= 2 nothing (an
+        //                 out-of-range offset).  16-byte loads instead of 8-byte ones, no unpacking: 287 -> 214 us on the
+        //                 64-channel 192x192 layers of W48, which are HBM-bound.  (Tried for the split format too, hi and lo
+        //                 chunks in g < 2 / g >= 2: correct, ~70 VALU instructions fewer per item, but the selector's 4
+        //                 registers pushed the kernel from 2 to 18 spilled VGPRs and every layer lost 10-15 %.)
         constexpr int NH = NT >= 2 ? NT / 2 : 1;
         u32x4 rc[NH];
         const int rfl = relu_floor(relu);                        // branch-free optional ReLU (see sb.h)
         const bool do_res = !(S2_ABL & 128) && last_chunk && p.res != nullptr;
+        const int ctb = (ct * MW + mw) * 16;                    // first cout of the wave's tile (no residual in multi-head launches)
+        const uint32_t r0 = !BF ? o0 : (rox < p.OW && g < 2 ? (uint32_t)((roy * p.OW + rox) * opix + (ctb + 8 * g) * 2) : OOB);
         auto res_load = [&](int half) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < NH; ++t) {
                 const int tt = half * NH + t;
-                const uint32_t ro_ = (tt < NT && tt < nrows && (!S2_STATIC_LOADS || do_res)) ? o0 + (uint32_t)(tt * orow) : OOB;
-                if (BF) {
-                    const auto r2 = __builtin_amdgcn_raw_buffer_load_b64(rr, (int)ro_, yso, 0);
-                    rc[t] = u32x4{r2[0], r2[1], 0u, 0u};
-                } else {
-                    rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ro_, yso, 0);
-                }
+                const uint32_t ro_ = (tt < NT && tt < nrows && (!S2_STATIC_LOADS || do_res)) ? r0 + (uint32_t)(tt * orow) : OOB;
+                rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ro_, yso, 0);
             }
         };
-        auto res_of = [&](int t, float r_[4]) __attribute__((always_inline)) {
+        // bf16 format: the selector A[r][k] = 1 where k = 8g + j is cout r of the tile (g < 2).  Rebuilt in every step
+        // that folds a residual (8 VALU) instead of living in 4 VGPRs for the whole launch (the empty asm pins it here).
+        u32x4 idw = {0u, 0u, 0u, 0u};
+        if (BF && do_res) {
+            int jj = (lane & 15) - 8 * g;
+            asm volatile("" : "+v"(jj));
+            const uint32_t one = (jj & 1) ? 0x3f800000u : 0x00003f80u;
+            const bool on = jj >= 0 && jj < 8 && g < 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) idw[k] = (on && (jj >> 1) == k) ? one : 0u;
+        }
+        const bf16x8 idA = __builtin_bit_cast(bf16x8, idw);
+        auto res_fold = [&](int t) __attribute__((always_inline)) {          // acc[t] += residual row t (its chunk in rc[t % NH])
             if (BF) {
-                unpack4_bf16(make_uint2(rc[t][0], rc[t][1]), r_);
-                return;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(idA, __builtin_bit_cast(bf16x8, rc[t % NH]), acc[t], 0, 0, 0);
+            } else {
+                uint2 rh_, rl_;
+                chunk_to_quad(make_uint4(rc[t % NH][0], rc[t % NH][1], rc[t % NH][2], rc[t % NH][3]), rh_, rl_);
+                float r_[4];
+                join4(rh_, rl_, r_);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] += r_[i];
             }
-            uint2 rh_, rl_;
-            chunk_to_quad(make_uint4(rc[t][0], rc[t][1], rc[t][2], rc[t][3]), rh_, rl_);
-            join4(rh_, rl_, r_);
         };
         auto epilogue_row = [&](int t, auto res_c) __attribute__((always_inline)) {
+            if (!BF && decltype(res_c)::value && NT >= 2 && t >= NH) res_fold(t);
             float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-            if (decltype(res_c)::value && NT >= 2 && t >= NH) {
-                float r_[4];
-                res_of(t - NH, r_);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] += r_[i];
-            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = relu_opt(v[i], rfl);
             const uint32_t so_ = t < nrows ? o0 + (uint32_t)(t * orow) : OOB;
@@ -411,6 +430,8 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p,
                             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xo, acc[t], 0, 0, 0);
                             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ky * 3 + kx], xh, acc[t], 0, 0, 0);
                         }
+                        // the row's last MFMA of the item: the second half of the residual rows rides behind it
+                        if (BF && decltype(res_c)::value && kx == 2 && ky == 2 && NT >= 2 && t >= NH) res_fold(t);
                     }
                 }
             }
@@ -431,12 +452,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p,
         if (reload) S2_LOAD_W(nct, nch, 1)
         if (do_res) {
 #pragma unroll
-            for (int t = 0; t < NH; ++t) {
-                float r_[4];
-                res_of(t, r_);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t][i] += r_[i];
-            }
+            for (int t = 0; t < NH; ++t) res_fold(t);
             if (!S2_STATIC_LOADS && NT >= 2) res_load(1);
         }
         if (S2_STATIC_LOADS && NT >= 2) res_load(1);
