@@ -555,6 +555,9 @@ Choice choose_conv(const ConvParams& p, int k, int stride) {
 }
 }  // namespace
 
+// does launch_conv run the stride-1 stream kernel for this 3x3 convolution?
+bool conv_is_stream_s1(const ConvParams& p) { return choose_conv(p, 3, 1) == C_STREAM_S1; }
+
 int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
     switch (choose_conv(p, k, stride)) {
         case C_STREAM_S1: return launch_conv_s1w(p, stream);

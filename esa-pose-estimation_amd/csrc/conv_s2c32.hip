@@ -99,8 +99,10 @@ __device__ __forceinline__ int div_magic(int b, int d, uint32_t m) {
 // and retires the reads of step s at once.  (Single-buffered: barrier, write, barrier, and the LDS-read pipe starts
 // cold behind the second one.)
 // OCC: workgroups per CU the register budget is cut for (2: 256 VGPRs per wave; 1: 512 — the 16-row tile).
-template <int S, int TH, int MW, bool MH = false, bool BF = false, bool DB = false, int OCC = 2>
-__global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p, StreamGeo geo) {
+// The body is shared by the one-convolution kernel and by conv_s2c32_jobs_kernel (several independent convolutions in
+// one launch): `bid` / `G` are the workgroup's index and the grid size WITHIN its convolution.
+template <int S, int TH, int MW, bool MH, bool BF, bool DB, int OCC>
+__device__ __forceinline__ void conv_s2c32_body(const ConvParams& p, const StreamGeo& geo, const int bid, const int G) {
     using S2C = ConvCfg<3, S, TH, 2>;
     constexpr int RG = 4 / MW;                  // row groups
     constexpr int NT = TH / RG;                 // output rows per wave
@@ -117,19 +119,18 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4;
     const int mw = wave % MW, rg = wave / MW;
-    const int G = gridDim.x;
     constexpr int EB = BF ? 2 : 4;             // bytes per channel
     const int nchunks = p.Cinp >> (BF ? 6 : 5);
     const int pixb = p.Cinp * EB;
     int opix = p.Coutp * EB;                                             // (per item in a multi-head launch)
     const int ximg = p.H * p.W * pixb;
     int yimg = p.OH * p.OW * opix;                                       // bytes per image (< 2^31, host-checked)
-    int item = xcd_contiguous(blockIdx.x, G);
+    int item = xcd_contiguous(bid, G);
     if (item >= geo.nitems) return;
 #ifdef S2_TRACE
     const unsigned long long t_begin = clock64();
-    const bool wgon = S == 1 && p.Cinp == S2_TRACE && blockIdx.x < 1024 && tid == 0;
-    if (wgon) g_s2_wg[blockIdx.x * 2] = wall_clock64();
+    const bool wgon = S == 1 && p.Cinp == S2_TRACE && bid < 1024 && tid == 0;
+    if (wgon) g_s2_wg[bid * 2] = wall_clock64();
 #endif
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (uint32_t)p.N * (uint32_t)ximg);
     __amdgpu_buffer_rsrc_t ry = make_rsrc(MH ? p.yh[0] : p.y, (uint32_t)p.N * (uint32_t)yimg);
@@ -223,8 +224,8 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p,
 #ifdef S2_TRACE
     int tstep = 0;
     // traced: the first 32 workgroups and the first 32 of the second half (the second workgroup of a CU)
-    const int tslot = (int)blockIdx.x < 32 ? (int)blockIdx.x : (int)blockIdx.x - (G >> 1) + 32;
-    const bool ton = S == 1 && p.Cinp == S2_TRACE && tslot >= 0 && tslot < 64 && ((int)blockIdx.x < 32 || (int)blockIdx.x >= (G >> 1)) && lane == 0;
+    const int tslot = bid < 32 ? bid : bid - (G >> 1) + 32;
+    const bool ton = S == 1 && p.Cinp == S2_TRACE && tslot >= 0 && tslot < 64 && (bid < 32 || bid >= (G >> 1)) && lane == 0;
     unsigned long long* const trow = g_s2_trace + ((ton ? tslot : 0) * 4 + wave) * 8 * 16;
 #define TR(EV) if (ton && tstep < 8) trow[tstep * 16 + (EV)] = clock64();
     if (ton) {
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p,
             }
 #endif
 #ifdef S2_TRACE
-            if (wgon && !more) g_s2_wg[blockIdx.x * 2 + 1] = wall_clock64();
+            if (wgon && !more) g_s2_wg[bid * 2 + 1] = wall_clock64();
 #endif
             if (!more) break;
             if (nct != ct) bv = *reinterpret_cast<const f32x4*>(p.bias + (nct * MW + mw) * 16 + g * 4);
@@ -501,6 +502,40 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p,
     }
 #undef TR
 #undef S2_LOAD_W
+}
+
+template <int S, int TH, int MW, bool MH = false, bool BF = false, bool DB = false, int OCC = 2>
+__global__ __launch_bounds__(NTHREADS, OCC) void conv_s2c32_kernel(ConvParams p, StreamGeo geo) {
+    conv_s2c32_body<S, TH, MW, MH, BF, DB, OCC>(p, geo, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several INDEPENDENT convolutions (the same-depth 3x3s of the 64/128/256-channel branches of an HRModule,
+// models/seg_hrnet.py:143-174: the branches do not talk to each other between two fuse layers) in one launch.
+// Workgroups [start[j], start[j+1]) run convolution j exactly as its own launch would — same items per workgroup,
+// same order, same bits — but the launch gap is paid once, the 256-channel convolution (one workgroup per CU on its
+// own, i.e. one wave per SIMD) shares the CUs with the others, and one convolution's tail overlaps the next one's
+// start.  Longest workgroups first (the dispatcher hands out workgroups in index order).
+// A convolution with a multiple of 64 couts runs the 64-cout tiling (MW = 4), one with 32 (mod 64) the 32-cout one (MW = 2):
+// both bodies live in the kernel, a workgroup takes the one its convolution needs.  The 32-channel branch's convolutions
+// are HBM-bound (67 MB in, 67 MB out for 9.7 GFLOP), the deeper branches' matrix-bound: side by side on the CUs they
+// overlap instead of adding up.
+constexpr int MAXJOBS = 4;
+struct StreamJobs {
+    ConvParams p[MAXJOBS];
+    StreamGeo geo[MAXJOBS];
+    int start[MAXJOBS + 1];
+    int mw[MAXJOBS];
+    int njobs;
+};
+template <int S, int TH, bool BF>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_s2c32_jobs_kernel(StreamJobs jobs) {
+    const int b = (int)blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < MAXJOBS; ++k) j += (k < jobs.njobs && b >= jobs.start[k]) ? 1 : 0;
+    const int bid = b - jobs.start[j], G = jobs.start[j + 1] - jobs.start[j];
+    if (!BF && jobs.mw[j] == 2) conv_s2c32_body<S, TH, 2, false, BF, false, 2>(jobs.p[j], jobs.geo[j], bid, G);
+    else conv_s2c32_body<S, TH, 4, false, BF, false, 2>(jobs.p[j], jobs.geo[j], bid, G);
 }
 
 uint32_t magic_of(int d) { return (uint32_t)(0xffffffffull / (uint64_t)d); }
@@ -641,6 +676,68 @@ int launch_conv_s1w(const ConvParams& p, hipStream_t stream) {
 #endif
     if (p.Coutp % 64 == 0) return launch_s2c32_t<1, 8, 4>(p, stream);
     return launch_s2c32_t<1, 8, 2>(p, stream);
+}
+
+// ---- several independent stride-1 convolutions in one launch (conv_s2c32_jobs_kernel) ----------------------------
+bool conv_jobs_supported(const ConvParams* ps, int n, int stride) {
+    if (n < 2 || n > MAXJOBS || (stride != 1 && stride != 2)) return false;
+    for (int j = 0; j < n; ++j) {
+        const ConvParams& p = ps[j];
+        if (p.bf != ps[0].bf || p.nheads > 1 || p.out_f32 || p.Coutp % (p.bf ? 64 : 32) != 0 || !conv_s2c32_supported(p)) return false;
+        if (images_per_launch(p) < p.N || (stride == 1 && (p.H != p.OH || p.W != p.OW || use_th16(p)))) return false;
+        if (stride == 2 && (p.OH != (p.H + 1) / 2 || p.OW != (p.W + 1) / 2 || p.res)) return false;
+    }
+    return true;
+}
+
+template <int S, int TH, bool BF>
+static int launch_jobs_t(const ConvParams* ps, int n, hipStream_t stream) {
+    using S2C = ConvCfg<3, S, TH, 2>;
+    StreamJobs jobs{};
+    const int slots = 2 * device_cus();
+    struct J { int idx, grid; long long steps; };
+    J order[MAXJOBS];
+    StreamGeo geos[MAXJOBS];
+    int mws[MAXJOBS];
+    for (int j = 0; j < n; ++j) {
+        const ConvParams& p = ps[j];
+        StreamGeo& geo = geos[j];
+        geo.tiles_x = (p.OW + TW - 1) / TW;
+        geo.tiles_y = (p.OH + TH - 1) / TH;
+        const int mw = p.Coutp % 64 == 0 ? 4 : 2;
+        mws[j] = mw;
+        geo.ctiles = p.Coutp / (16 * mw);
+        const long long nitems = (long long)p.N * geo.tiles_y * geo.tiles_x * geo.ctiles;
+        if (nitems <= 0 || nitems > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        geo.nitems = (int)nitems;
+        geo.m_ct = magic_of(geo.ctiles);
+        geo.m_tx = magic_of(geo.tiles_x);
+        geo.m_ty = magic_of(geo.tiles_y);
+        int grid = (int)(nitems < slots ? nitems : slots);
+        if (grid > geo.ctiles) grid -= grid % geo.ctiles;
+        order[j] = {j, grid, ((nitems + grid - 1) / grid) * (p.Cinp >> (BF ? 6 : 5))};
+    }
+    std::sort(order, order + n, [](const J& a, const J& b) { return a.steps > b.steps; });   // longest workgroups first
+    jobs.njobs = n;
+    int at = 0;
+    for (int k = 0; k < n; ++k) {
+        jobs.p[k] = ps[order[k].idx];
+        jobs.geo[k] = geos[order[k].idx];
+        jobs.mw[k] = mws[order[k].idx];
+        jobs.start[k] = at;
+        at += order[k].grid;
+    }
+    for (int k = n; k <= MAXJOBS; ++k) jobs.start[k] = at;
+    auto kern = conv_s2c32_jobs_kernel<S, TH, BF>;
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), S2C::XBYTES)) return e_;
+    hipLaunchKernelGGL(kern, dim3((unsigned)at), dim3(NTHREADS), S2C::XBYTES, stream, jobs);
+    return (int)hipGetLastError();
+}
+
+int launch_conv_jobs(const ConvParams* ps, int n, int stride, hipStream_t stream) {
+    if (!conv_jobs_supported(ps, n, stride)) return (int)hipErrorInvalidValue;
+    if (stride == 1) return ps[0].bf ? launch_jobs_t<1, 8, true>(ps, n, stream) : launch_jobs_t<1, 8, false>(ps, n, stream);
+    return ps[0].bf ? launch_jobs_t<2, 4, true>(ps, n, stream) : launch_jobs_t<2, 4, false>(ps, n, stream);
 }
 
 }  // namespace esa

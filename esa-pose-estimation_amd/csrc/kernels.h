@@ -41,6 +41,10 @@ const char* conv_kernel_name(const ConvParams& p, int k, int stride);
 bool conv_s2c32_supported(const ConvParams& p);
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream);
 int launch_conv_s1w(const ConvParams& p, hipStream_t stream);
+bool conv_is_stream_s1(const ConvParams& p);       // launch_conv(p, 3, 1) runs the stride-1 stream kernel
+// 2..4 independent 3x3 convolutions of one stride (each one a stream-kernel launch on its own) as ONE launch
+bool conv_jobs_supported(const ConvParams* ps, int n, int stride);
+int launch_conv_jobs(const ConvParams* ps, int n, int stride, hipStream_t stream);
 bool use_th16(const ConvParams& p);               // stride-1 stream kernel: 16-row tile, one workgroup per CU (conv_s2c32.hip)
 void set_stream_launch_limit(long long bytes);     // test hook, see conv_s2c32.hip images_per_launch
 // 1x1, Cinp in {64..384}: all input channels of 16 pixels in registers, weights streamed through LDS (conv1x1.hip)

@@ -109,6 +109,8 @@ struct Op {
     int align = 0;              // OP_RESAMPLE: align_corners
     int alt = 0;                // 0: always; 1: head_fused path only; 2: head_fused2 path only (chosen per shape)
     int multi = -1, mpos = 0;   // OP_CONV: member mpos of multi-head group `multi` (mpos 0 launches for all members)
+    int jkey = -1;              // OP_CONV of an HRModule branch: (module id << 8) | position along the branch's conv chain
+    int job = -1, jpos = 0;     // member jpos of job group `job` (independent same-depth convs of several branches, one launch)
 };
 
 // stride-2 3x3 convolutions of the SAME input tensor (the first links of the fuse-down chains of a stage), evaluated
@@ -121,6 +123,13 @@ struct Multi {
     int coutp = 0;
 };
 
+// the same-depth 3x3 convolutions of the branches of one HRModule: independent, evaluated by one launch of the stream
+// kernel's multi-convolution form where every member is a 64-cout stream launch at the shape at hand
+struct JobGroup {
+    int n = 0;
+    int op[4] = {-1, -1, -1, -1};   // op indices, consecutive: op[0] = leader
+};
+
 struct ShapePlan {
     int n = 0, h = 0, w = 0;
     bool keep = false;
@@ -129,6 +138,7 @@ struct ShapePlan {
     bool head2 = false;         // this shape runs the second-generation head (ops with alt == 2)
     bool head2_ulo = false;     // ... with the lo part of the interpolation weights
     std::vector<char> multi_on; // per Multi: evaluated as one launch at this shape
+    std::vector<char> job_on;   // per JobGroup: evaluated as one launch at this shape
 };
 
 }  // namespace
@@ -175,6 +185,7 @@ struct esahrnet_ctx {
     ShapePlan sp;
     int max_level = 0;
     std::vector<Multi> multis;
+    std::vector<JobGroup> jobs;
 };
 
 namespace {
@@ -182,6 +193,8 @@ namespace {
 struct Builder {
     esahrnet_ctx& c;
     int lane = 0;               // lane given to the ops being appended
+    int jkey = -1;              // job key given to the next stride-1 convolutions (HRModule branches), -1: none
+    int jkey2 = -1;             // job key given to the next stride-2 convolution (fuse-down chain link), -1: none
     explicit Builder(esahrnet_ctx& ctx) : c(ctx) {}
 
     int spec(const std::string& name, const std::string& bn, int cin, int cout, int k, int stride,
@@ -214,6 +227,8 @@ struct Builder {
         c.dconvs.push_back(d);
         Op o;
         o.kind = OP_CONV; o.dconv = (int)c.dconvs.size() - 1; o.in = in; o.res = res; o.relu = relu; o.lane = lane;
+        if (jkey >= 0 && s.k == 3 && s.stride == 1) o.jkey = jkey++;
+        if (jkey2 >= 0 && s.k == 3 && s.stride == 2) o.jkey = jkey2;
         // ESAHRNET_TAP_ALL=1 (debugging): every convolution output becomes a named tap
         o.out = tensor(s.cout, s.level, tap.empty() && !out_f32 && getenv("ESAHRNET_TAP_ALL") ? "conv:" + s.name : tap);
         const int idx = (int)c.ops.size();
@@ -293,7 +308,10 @@ struct Builder {
         int res = x;
         const int c1 = spec(p + ".conv1", p + ".bn1", cin, cout, 3, 1, level, false, true);
         const int c2 = spec(p + ".conv2", p + ".bn2", cout, cout, 3, 1, level, false, true);
-        if (c.fuse_big && cin == cout && pad32(cin) == 32) {     // whole block in one kernel (bblock32.hip)
+        // whole block in one kernel (bblock32.hip) — for layer1; inside the HRModules the block's two convolutions join the
+        // same-depth convolutions of the other branches in one launch instead (group_jobs; ESAHRNET_NO_JOBS=1: fused block)
+        const bool in_job = jkey >= 0 && !getenv("ESAHRNET_NO_JOBS");
+        if (c.fuse_big && cin == cout && pad32(cin) == 32 && !getenv("ESAHRNET_NO_BBLOCK") && !in_job) {
             Op o;
             o.kind = OP_BLOCK; o.in = x; o.relu = true; o.lane = lane;
             for (int k = 0; k < 2; ++k) {
@@ -375,10 +393,67 @@ void group_multihead(esahrnet_ctx& c) {
     }
 }
 
+// Post-pass: inside one HRModule the branches are independent chains of 3x3 convolutions.  The builder emits them
+// branch by branch; here the convolutions of a module are put in depth-major order (stable, so every branch keeps its own
+// order) and the same-depth ones of up to three branches become a JobGroup.
+void group_jobs(esahrnet_ctx& c) {
+    if (getenv("ESAHRNET_NO_JOBS") || c.nlanes > 1) return;
+    std::vector<Op> ops = c.ops;
+    auto eligible = [&](const Op& o) {
+        if (o.kind != OP_CONV || o.jkey < 0 || o.alt != 0 || o.multi >= 0) return false;
+        const DevConv& d = c.dconvs[o.dconv];
+        const ConvSpec& s = c.specs[d.spec];
+        return s.k == 3 && !d.out_f32 && d.c0 == 0 && d.c1 == s.cin && d.perm.empty() && d.use_bias &&
+               d.coutp % (c.bf ? 64 : 32) == 0;
+    };
+    size_t i = 0;
+    while (i < ops.size()) {
+        if (ops[i].jkey < 0) { ++i; continue; }
+        const int mod = ops[i].jkey >> 8;
+        size_t j = i;
+        while (j < ops.size() && ops[j].jkey >= 0 && (ops[j].jkey >> 8) == mod) ++j;      // [i, j): this module's branch convs
+        std::stable_sort(ops.begin() + i, ops.begin() + j, [](const Op& a, const Op& b) { return (a.jkey & 255) < (b.jkey & 255); });
+        for (size_t a = i; a < j;) {
+            size_t b = a;
+            std::vector<size_t> mem;
+            while (b < j && ops[b].jkey == ops[a].jkey) { if (eligible(ops[b]) && mem.size() < 4) mem.push_back(b); ++b; }
+            // members must be consecutive for the leader to stand for them: move the ineligible ones of this depth behind
+            if (mem.size() >= 2) {
+                std::vector<Op> grp, rest;
+                for (size_t k = a; k < b; ++k) (std::find(mem.begin(), mem.end(), k) != mem.end() ? grp : rest).push_back(ops[k]);
+                JobGroup g;
+                g.n = (int)grp.size();
+                for (int k = 0; k < g.n; ++k) { grp[k].job = (int)c.jobs.size(); grp[k].jpos = k; g.op[k] = (int)(a + k); }
+                std::copy(grp.begin(), grp.end(), ops.begin() + a);
+                std::copy(rest.begin(), rest.end(), ops.begin() + a + grp.size());
+                c.jobs.push_back(g);
+            }
+            a = b;
+        }
+        i = j;
+    }
+    c.ops = ops;
+    for (Tensor& t : c.tensors) { t.def = -1; t.last = -1; }
+    c.head2_op = -1;
+    for (size_t k = 0; k < c.ops.size(); ++k) {
+        const Op& o = c.ops[k];
+        if (o.kind == OP_HEAD2 || o.kind == OP_HEADBF) c.head2_op = (int)k;
+        if (o.out >= 0 && c.tensors[o.out].def < 0) c.tensors[o.out].def = (int)k;
+        auto use = [&](int t) { if (t >= 0) c.tensors[t].last = std::max(c.tensors[t].last, (int)k); };
+        use(o.in); use(o.res);
+        for (int t = 0; t < 4; ++t) use(o.terms[t]);
+    }
+    // the multi-head groups refer to op indices too
+    for (Multi& m : c.multis) m.n = 0;
+    for (size_t k = 0; k < c.ops.size(); ++k)
+        if (c.ops[k].multi >= 0) { Multi& m = c.multis[c.ops[k].multi]; m.op[c.ops[k].mpos] = (int)k; m.n = std::max(m.n, c.ops[k].mpos + 1); }
+}
+
 int build_plan_ops(esahrnet_ctx& c);
 int build_plan(esahrnet_ctx& c) {
     if (build_plan_ops(c)) return 1;
     group_multihead(c);
+    group_jobs(c);
     return 0;
 }
 
@@ -463,32 +538,42 @@ int build_plan_ops(esahrnet_ctx& c) {
             const std::string p = "stage" + std::to_string(s) + "." + std::to_string(m);
             for (int b = 0; b < nb; ++b) {
                 B.lane = b;                  // the branches of a stage are independent chains
-                for (int k = 0; k < g.blocks[s - 1][b]; ++k)
+                for (int k = 0; k < g.blocks[s - 1][b]; ++k) {
+                    B.jkey = (((s << 4) | m) << 8) | (2 * k);       // conv1 / conv2 of block k take 2k / 2k + 1
                     xs[b] = B.basic_block(p + ".branches." + std::to_string(b) + "." + std::to_string(k),
                                           xs[b], cur[b], cur[b], 1 + b, "");
+                    B.jkey = -1;
+                }
             }
-            std::vector<int> outs;
+            // fuse layers (:176-220, :232-247).  Emitted family by family, not output branch by output branch, so that
+            // independent launches of one kernel family stand next to each other (group_jobs / group_multihead merge them):
+            // all 1x1 fuse-up convolutions, then the stride-2 fuse-down chains link by link, then the sums.
+            std::vector<std::vector<int>> terms(nb, std::vector<int>(nb, -1));
+            const int modkey = ((s << 4) | m) << 8;
             for (int i = 0; i < nb; ++i) {
                 B.lane = i;                  // everything that feeds output branch i runs on lane i
-                std::vector<int> terms;
-                for (int j = 0; j < nb; ++j) {
+                terms[i][i] = xs[i];
+                for (int j = i + 1; j < nb; ++j) {      // 1x1 + BN on the low-res grid; up-sampled inside fuse
                     const std::string q = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j);
-                    if (j == i) {
-                        terms.push_back(xs[j]);
-                    } else if (j > i) {          // 1x1 + BN on the low-res grid; up-sampled inside fuse
-                        terms.push_back(B.conv(B.spec(q + ".0", q + ".1", cur[j], cur[i], 1, 1, 1 + j, false, false), xs[j], -1, false));
-                    } else {                     // chain of 3x3 s2 (:198-217)
-                        int tt = xs[j];
-                        for (int k = 0; k < i - j; ++k) {
-                            const bool last = k == i - j - 1;
-                            const std::string qq = q + "." + std::to_string(k);
-                            tt = B.conv(B.spec(qq + ".0", qq + ".1", cur[j], last ? cur[i] : cur[j], 3, 2, 1 + j + k + 1, false, !last), tt, -1, !last);
-                        }
-                        terms.push_back(tt);
-                    }
+                    terms[i][j] = B.conv(B.spec(q + ".0", q + ".1", cur[j], cur[i], 1, 1, 1 + j, false, false), xs[j], -1, false);
                 }
+            }
+            for (int k = 0; k + 1 < nb; ++k)            // link k of every chain of 3x3 s2 (:198-217) that has one
+                for (int i = k + 1; i < nb; ++i)
+                    for (int j = 0; j + k < i; ++j) {
+                        B.lane = i;
+                        const bool last = k == i - j - 1;
+                        const std::string qq = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j) + "." + std::to_string(k);
+                        const int sp_ = B.spec(qq + ".0", qq + ".1", cur[j], last ? cur[i] : cur[j], 3, 2, 1 + j + k + 1, false, !last);
+                        B.jkey2 = modkey | (128 + k);
+                        terms[i][j] = B.conv(sp_, k == 0 ? xs[j] : terms[i][j], -1, !last);
+                        B.jkey2 = -1;
+                    }
+            std::vector<int> outs;
+            for (int i = 0; i < nb; ++i) {
+                B.lane = i;
                 const bool final_module = m == g.modules[s - 1] - 1;
-                outs.push_back(B.fuse(terms, cur[i], 1 + i, true,
+                outs.push_back(B.fuse(terms[i], cur[i], 1 + i, true,
                                       final_module ? "stage" + std::to_string(s) + "." + std::to_string(i) : ""));
             }
             xs = outs;
@@ -698,6 +783,37 @@ bool multi_on_for(const esahrnet_ctx& c, const Multi& m, int n, const std::vecto
     return esa::conv_s2c32_multi_supported(q);
 }
 
+// ConvParams of a convolution op at a shape; `ws` == nullptr: shapes and flags only (pointers that are merely tested
+// against nullptr get a non-null dummy)
+esa::ConvParams conv_params_of(const esahrnet_ctx& c, const Op& o, int n, const std::vector<int>& lh, const std::vector<int>& lw,
+                               char* ws) {
+    const DevConv& d = c.dconvs[o.dconv];
+    const Tensor& ti = c.tensors[o.in];
+    const Tensor& to = c.tensors[o.out];
+    esa::ConvParams p{};
+    char* dummy = reinterpret_cast<char*>(const_cast<esahrnet_ctx*>(&c));
+    p.x = ws ? ws + ti.off : dummy;
+    p.y = ws ? ws + to.off : dummy;
+    p.res = o.res >= 0 ? (ws ? ws + c.tensors[o.res].off : dummy) : nullptr;
+    p.w = static_cast<const uint4*>(d.w); p.bias = d.bias;
+    p.N = n; p.H = lh[ti.level]; p.W = lw[ti.level]; p.OH = lh[to.level]; p.OW = lw[to.level];
+    p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu; p.out_f32 = d.out_f32; p.bf = c.bf ? 1 : 0;
+    return p;
+}
+
+// is this job group evaluated as ONE launch at this shape?  Every member must be a stream-kernel launch of its own
+// there (the kernel serving a layer depends on the shape only, never on the grouping)
+bool job_on_for(const esahrnet_ctx& c, const JobGroup& g, int n, const std::vector<int>& lh, const std::vector<int>& lw) {
+    esa::ConvParams ps[4];
+    for (int k = 0; k < g.n; ++k) {
+        ps[k] = conv_params_of(c, c.ops[g.op[k]], n, lh, lw, nullptr);
+        const int stride = c.specs[c.dconvs[c.ops[g.op[k]].dconv].spec].stride;
+        if (stride != c.specs[c.dconvs[c.ops[g.op[0]].dconv].spec].stride) return false;
+        if (stride == 1 && !esa::conv_is_stream_s1(ps[k])) return false;
+    }
+    return esa::conv_jobs_supported(ps, g.n, c.specs[c.dconvs[c.ops[g.op[0]].dconv].spec].stride);
+}
+
 int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
     if (c.sp.n == n && c.sp.h == h && c.sp.w == w && c.sp.keep == c.keep) return 0;
     if (check_shape(c, n, h, w)) return 1;
@@ -708,6 +824,8 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
     const int active_alt = sp.head2 ? 2 : 1;
     sp.multi_on.assign(c.multis.size(), 0);
     for (size_t mi = 0; mi < c.multis.size(); ++mi) sp.multi_on[mi] = multi_on_for(c, c.multis[mi], n, sp.lh, sp.lw) ? 1 : 0;
+    sp.job_on.assign(c.jobs.size(), 0);
+    for (size_t ji = 0; ji < c.jobs.size(); ++ji) sp.job_on[ji] = job_on_for(c, c.jobs[ji], n, sp.lh, sp.lw) ? 1 : 0;
     struct Free { size_t off, len; };
     std::vector<Free> free_list;
     size_t top = 0;
@@ -777,10 +895,19 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
                     for (int a : accessors[r.tensor]) if (a < (int)oi) deps[oi].push_back(a);
             high = std::max(high, std::max(top, off + len));
         }
+        // a job group runs as ONE launch: what one member reads last must not be handed to another member's output, so a
+        // tensor whose last reader sits inside a group stays alive until the group's last member
+        auto last_of = [&](const Tensor& t) {
+            if (t.last >= 0 && c.ops[t.last].job >= 0) {
+                const JobGroup& g = c.jobs[c.ops[t.last].job];
+                return g.op[g.n - 1];
+            }
+            return t.last;
+        };
         if (!c.keep)
             for (size_t ti = 0; ti < c.tensors.size(); ++ti) {
                 Tensor& t = c.tensors[ti];
-                if (allocated[ti] && t.last == (int)oi) {
+                if (allocated[ti] && last_of(t) == (int)oi) {
                     release(t.off, bytes_of(t));
                     retired.push_back({t.off, bytes_of(t), (int)ti});
                 }
@@ -1246,12 +1373,15 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                     rc = esa::launch_conv_s2c32_multi(p, stream);
                     break;
                 }
-                esa::ConvParams p{};
-                p.x = T(o.in); p.y = T(o.out); p.res = o.res >= 0 ? T(o.res) : nullptr;
-                p.w = static_cast<const uint4*>(d.w); p.bias = d.bias;
-                p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level];
-                p.OH = sp.lh[to.level]; p.OW = sp.lw[to.level];
-                p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu; p.out_f32 = d.out_f32; p.bf = h->bf ? 1 : 0;
+                if (o.job >= 0 && sp.job_on[o.job]) {
+                    if (o.jpos > 0) break;                      // evaluated by the group's leader
+                    const JobGroup& g = h->jobs[o.job];
+                    esa::ConvParams ps[4];
+                    for (int k = 0; k < g.n; ++k) ps[k] = conv_params_of(*h, h->ops[g.op[k]], n, sp.lh, sp.lw, ws);
+                    rc = esa::launch_conv_jobs(ps, g.n, s.stride, stream);
+                    break;
+                }
+                const esa::ConvParams p = conv_params_of(*h, o, n, sp.lh, sp.lw, ws);
                 rc = esa::launch_conv(p, s.k, s.stride, stream);
                 break;
             }
@@ -1469,6 +1599,27 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                     lab += (k ? " + " : "") + sk.name;
                     out->flops += 2.0 * n * lh[tk.level] * lw[tk.level] * sk.cout * sk.cin * 9.0;
                     out->bytes += tbytes(ok.out) + (double)esa::packed_weight_bytes(dk.coutp, dk.cinp, 3);
+                }
+                snprintf(out->label, sizeof out->label, "%s", lab.c_str());
+                break;
+            }
+            if (o.job >= 0 && job_on_for(*h, h->jobs[o.job], n, lh, lw)) {
+                const JobGroup& g = h->jobs[o.job];
+                if (o.jpos > 0) {        // no launch of its own
+                    snprintf(out->label, sizeof out->label, "%s (in the merged launch above)", s.name.c_str());
+                    break;
+                }
+                snprintf(out->kernel, sizeof out->kernel, "conv_s2c32_jobs_kernel<%d, %d, %s>", s.stride, s.stride == 1 ? 8 : 4, h->bf ? "true" : "false");
+                std::string lab;
+                for (int k = 0; k < g.n; ++k) {
+                    const Op& ok = h->ops[g.op[k]];
+                    const DevConv& dk = h->dconvs[ok.dconv];
+                    const ConvSpec& sk = h->specs[dk.spec];
+                    const Tensor& tk = h->tensors[ok.out];
+                    lab += (k ? " + " : "") + sk.name;
+                    out->flops += 2.0 * n * lh[tk.level] * lw[tk.level] * sk.cout * sk.cin * 9.0;
+                    out->bytes += tbytes(ok.in) + tbytes(ok.out) + (ok.res >= 0 ? tbytes(ok.res) : 0.0) +
+                                  (double)(h->bf ? esa::packed_weight_bytes_bf(dk.coutp, dk.cinp, 3) : esa::packed_weight_bytes(dk.coutp, dk.cinp, 3));
                 }
                 snprintf(out->label, sizeof out->label, "%s", lab.c_str());
                 break;

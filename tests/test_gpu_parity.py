@@ -671,3 +671,25 @@ def test_dynamic_range_sweep(env):
         assert e / out <= 4.0e-5, (g_, e, out)          # relative error stays at the 2^-15..-16 level at every magnitude
         if g_ <= 1.0:
             assert e <= TOL, (g_, e)                    # the contract holds with margin at SURVEY's valid recipes
+
+
+@pytest.mark.parametrize("no_jobs", [False, True])
+def test_merged_branch_launches_and_their_fallback(env, golden_dir, monkeypatch, no_jobs):
+    """The same-depth 3x3 convolutions of an HRModule's branches (and the same-depth links of its fuse-down chains) are
+    independent and run as ONE launch of the stream kernel's multi-convolution form; ESAHRNET_NO_JOBS=1 keeps one launch
+    per convolution (and the fused 32-channel block).  Both must reproduce the reference; the op list says which ran."""
+    if no_jobs:
+        monkeypatch.setenv("ESAHRNET_NO_JOBS", "1")
+    g = np.load(os.path.join(golden_dir, "w32_hrnet2_128.npz"), allow_pickle=False)
+    net, sd = _build(env, "seg_hrnet2", tuple(int(v) for v in g["widths"]), int(g["seed"]))
+    x = env["synth"].make_crops(int(g["n"]), 1, int(g["hw"]), int(g["hw"]), seed=int(g["seed"]))
+    with torch.no_grad():
+        y, ops = net.forward_timed(x.cuda())
+    kernels = [o["kernel"] for o in ops]
+    assert any(k.startswith("conv_s2c32_jobs_kernel<1, 8") for k in kernels) == (not no_jobs)
+    assert (kernels.count("bblock32") == 9) == no_jobs                  # layer1.1 keeps the fused block either way
+    merged = [o for o in ops if o["kernel"].startswith("conv_s2c32_jobs_kernel")]
+    assert all(" + " in o["label"] and o["flops"] > 0 for o in merged)
+    print(f"launches: {len(ops)} ({len(merged)} merged)")
+    err = np.abs(y.cpu().numpy() - g["out"]).max()
+    assert err <= GUARD, err
