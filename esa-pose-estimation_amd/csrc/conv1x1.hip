@@ -18,13 +18,14 @@ namespace {
 
 // BF (ConvParams::bf): NCH counts 64-channel blocks of 128 bytes; the (hi, lo) fragment pair of a chunk becomes the
 // two K-steps of a block (sb.h), 2 MFMAs instead of 3, and the epilogue packs 4 channels into 8 bytes.
-template <int NCH, bool BF = false>
-__global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long ntiles, int tiles_per_row) {
+template <int NCH, bool BF>
+__device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long long ntiles, const int tiles_per_row,
+                                             const int bid, const int G) {
     constexpr int WFR = 4 * NCH;                   // 1-KB weight fragments per 32-cout chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const long long tile = (long long)xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
+    const long long tile = (long long)xcd_contiguous(bid, G) * 4 + wave;
     const bool live = tile < ntiles;
     const int k = (int)(tile % tiles_per_row);
     const long long row = tile / tiles_per_row;                 // n*H + y
@@ -108,6 +109,36 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long
 }
 
 template <int NCH, bool BF = false>
+__global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long ntiles, int tiles_per_row) {
+    conv1x1_body<NCH, BF>(p, ntiles, tiles_per_row, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several independent 1x1 convolutions in one launch (the fuse-up convolutions of an HRModule, models/seg_hrnet.py:
+// 176-197: each reads one branch, none reads another's output).  Workgroups [start[j], start[j+1]) run convolution j as
+// its own launch would; the body is instantiated for every input depth the plans have (2 / 4 / 8 chunks of 32 channels).
+constexpr int C1_MAXJOBS = 6;
+struct C1Jobs {
+    ConvParams p[C1_MAXJOBS];
+    long long ntiles[C1_MAXJOBS];
+    int tiles_per_row[C1_MAXJOBS];
+    int start[C1_MAXJOBS + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(256, 2) void conv1x1_jobs_kernel(C1Jobs jobs) {
+    const int b = (int)blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < C1_MAXJOBS; ++k) j += (k < jobs.njobs && b >= jobs.start[k]) ? 1 : 0;
+    const int bid = b - jobs.start[j], G = jobs.start[j + 1] - jobs.start[j];
+    const ConvParams& p = jobs.p[j];
+    switch (p.Cinp >> 5) {
+        case 2: conv1x1_body<2, false>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G); break;
+        case 4: conv1x1_body<4, false>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G); break;
+        default: conv1x1_body<8, false>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G); break;
+    }
+}
+
+template <int NCH, bool BF = false>
 int launch_conv1x1_n(const ConvParams& p, hipStream_t stream) {
     auto kern = conv1x1_kernel<NCH, BF>;
     const int lds = 2 * 4 * NCH * 1024;
@@ -158,6 +189,37 @@ int launch_conv1x1(const ConvParams& p, hipStream_t stream) {
         case 12: return launch_conv1x1_n<12>(p, stream);
     }
     return (int)hipErrorInvalidValue;
+}
+
+bool conv1x1_jobs_supported(const ConvParams* ps, int n) {
+    if (n < 2 || n > C1_MAXJOBS) return false;
+    for (int j = 0; j < n; ++j) {
+        const int nch = ps[j].Cinp / 32;
+        if (ps[j].bf || !conv1x1_supported(ps[j]) || (nch != 2 && nch != 4 && nch != 8)) return false;
+    }
+    return true;
+}
+
+int launch_conv1x1_jobs(const ConvParams* ps, int n, hipStream_t stream) {
+    if (!conv1x1_jobs_supported(ps, n)) return (int)hipErrorInvalidValue;
+    C1Jobs jobs{};
+    jobs.njobs = n;
+    int at = 0;
+    for (int j = 0; j < n; ++j) {
+        const ConvParams& p = ps[j];
+        jobs.p[j] = p;
+        jobs.tiles_per_row[j] = (p.W + 15) / 16;
+        jobs.ntiles[j] = (long long)p.N * p.H * jobs.tiles_per_row[j];
+        const long long nblk = (jobs.ntiles[j] + 3) / 4;
+        if (nblk <= 0 || at + nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        jobs.start[j] = at;
+        at += (int)nblk;
+    }
+    for (int k = n; k <= C1_MAXJOBS; ++k) jobs.start[k] = at;
+    const int lds = 2 * 4 * 8 * 1024;                 // the deepest body's two weight buffers
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(conv1x1_jobs_kernel), lds)) return e_;
+    hipLaunchKernelGGL(conv1x1_jobs_kernel, dim3((unsigned)at), dim3(256), lds, stream, jobs);
+    return (int)hipGetLastError();
 }
 
 }  // namespace esa

@@ -50,6 +50,9 @@ void set_stream_launch_limit(long long bytes);     // test hook, see conv_s2c32.
 // 1x1, Cinp in {64..384}: all input channels of 16 pixels in registers, weights streamed through LDS (conv1x1.hip)
 bool conv1x1_supported(const ConvParams& p);
 int launch_conv1x1(const ConvParams& p, hipStream_t stream);
+// 2..6 independent 1x1 convolutions (split format, 64 / 128 / 256 input channels) as ONE launch
+bool conv1x1_jobs_supported(const ConvParams* ps, int n);
+int launch_conv1x1_jobs(const ConvParams* ps, int n, hipStream_t stream);
 // bytes of the packed weight image for a conv with padded channel counts
 size_t packed_weight_bytes(int coutp, int cinp, int k);
 // host-side packing: w f32 [cout][cin][k][k] -> dst (packed_weight_bytes), zero padded

@@ -127,7 +127,7 @@ struct Multi {
 // kernel's multi-convolution form where every member is a 64-cout stream launch at the shape at hand
 struct JobGroup {
     int n = 0;
-    int op[4] = {-1, -1, -1, -1};   // op indices, consecutive: op[0] = leader
+    int op[6] = {-1, -1, -1, -1, -1, -1};   // op indices, consecutive: op[0] = leader
 };
 
 struct ShapePlan {
@@ -228,7 +228,7 @@ struct Builder {
         Op o;
         o.kind = OP_CONV; o.dconv = (int)c.dconvs.size() - 1; o.in = in; o.res = res; o.relu = relu; o.lane = lane;
         if (jkey >= 0 && s.k == 3 && s.stride == 1) o.jkey = jkey++;
-        if (jkey2 >= 0 && s.k == 3 && s.stride == 2) o.jkey = jkey2;
+        if (jkey2 >= 0 && ((s.k == 3 && s.stride == 2) || s.k == 1)) o.jkey = jkey2;
         // ESAHRNET_TAP_ALL=1 (debugging): every convolution output becomes a named tap
         o.out = tensor(s.cout, s.level, tap.empty() && !out_f32 && getenv("ESAHRNET_TAP_ALL") ? "conv:" + s.name : tap);
         const int idx = (int)c.ops.size();
@@ -403,6 +403,7 @@ void group_jobs(esahrnet_ctx& c) {
         if (o.kind != OP_CONV || o.jkey < 0 || o.alt != 0 || o.multi >= 0) return false;
         const DevConv& d = c.dconvs[o.dconv];
         const ConvSpec& s = c.specs[d.spec];
+        if (s.k == 1) return !c.bf && o.res < 0 && !d.out_f32 && d.c0 == 0 && d.c1 == s.cin && d.perm.empty() && d.use_bias;
         return s.k == 3 && !d.out_f32 && d.c0 == 0 && d.c1 == s.cin && d.perm.empty() && d.use_bias &&
                d.coutp % (c.bf ? 64 : 32) == 0;
     };
@@ -416,7 +417,8 @@ void group_jobs(esahrnet_ctx& c) {
         for (size_t a = i; a < j;) {
             size_t b = a;
             std::vector<size_t> mem;
-            while (b < j && ops[b].jkey == ops[a].jkey) { if (eligible(ops[b]) && mem.size() < 4) mem.push_back(b); ++b; }
+            const size_t cap = c.specs[c.dconvs[ops[a].dconv].spec].k == 1 ? 6 : 4;
+            while (b < j && ops[b].jkey == ops[a].jkey) { if (eligible(ops[b]) && mem.size() < cap) mem.push_back(b); ++b; }
             // members must be consecutive for the leader to stand for them: move the ineligible ones of this depth behind
             if (mem.size() >= 2) {
                 std::vector<Op> grp, rest;
@@ -555,7 +557,9 @@ int build_plan_ops(esahrnet_ctx& c) {
                 terms[i][i] = xs[i];
                 for (int j = i + 1; j < nb; ++j) {      // 1x1 + BN on the low-res grid; up-sampled inside fuse
                     const std::string q = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j);
+                    B.jkey2 = modkey | 200;             // all fuse-up 1x1 convolutions of the module are independent
                     terms[i][j] = B.conv(B.spec(q + ".0", q + ".1", cur[j], cur[i], 1, 1, 1 + j, false, false), xs[j], -1, false);
+                    B.jkey2 = -1;
                 }
             }
             for (int k = 0; k + 1 < nb; ++k)            // link k of every chain of 3x3 s2 (:198-217) that has one
@@ -804,7 +808,11 @@ esa::ConvParams conv_params_of(const esahrnet_ctx& c, const Op& o, int n, const 
 // is this job group evaluated as ONE launch at this shape?  Every member must be a stream-kernel launch of its own
 // there (the kernel serving a layer depends on the shape only, never on the grouping)
 bool job_on_for(const esahrnet_ctx& c, const JobGroup& g, int n, const std::vector<int>& lh, const std::vector<int>& lw) {
-    esa::ConvParams ps[4];
+    esa::ConvParams ps[6];
+    if (c.specs[c.dconvs[c.ops[g.op[0]].dconv].spec].k == 1) {
+        for (int k = 0; k < g.n; ++k) ps[k] = conv_params_of(c, c.ops[g.op[k]], n, lh, lw, nullptr);
+        return esa::conv1x1_jobs_supported(ps, g.n);
+    }
     for (int k = 0; k < g.n; ++k) {
         ps[k] = conv_params_of(c, c.ops[g.op[k]], n, lh, lw, nullptr);
         const int stride = c.specs[c.dconvs[c.ops[g.op[k]].dconv].spec].stride;
@@ -1376,9 +1384,9 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 if (o.job >= 0 && sp.job_on[o.job]) {
                     if (o.jpos > 0) break;                      // evaluated by the group's leader
                     const JobGroup& g = h->jobs[o.job];
-                    esa::ConvParams ps[4];
+                    esa::ConvParams ps[6];
                     for (int k = 0; k < g.n; ++k) ps[k] = conv_params_of(*h, h->ops[g.op[k]], n, sp.lh, sp.lw, ws);
-                    rc = esa::launch_conv_jobs(ps, g.n, s.stride, stream);
+                    rc = s.k == 1 ? esa::launch_conv1x1_jobs(ps, g.n, stream) : esa::launch_conv_jobs(ps, g.n, s.stride, stream);
                     break;
                 }
                 const esa::ConvParams p = conv_params_of(*h, o, n, sp.lh, sp.lw, ws);
@@ -1609,7 +1617,8 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                     snprintf(out->label, sizeof out->label, "%s (in the merged launch above)", s.name.c_str());
                     break;
                 }
-                snprintf(out->kernel, sizeof out->kernel, "conv_s2c32_jobs_kernel<%d, %d, %s>", s.stride, s.stride == 1 ? 8 : 4, h->bf ? "true" : "false");
+                if (s.k == 1) snprintf(out->kernel, sizeof out->kernel, "conv1x1_jobs_kernel");
+                else snprintf(out->kernel, sizeof out->kernel, "conv_s2c32_jobs_kernel<%d, %d, %s>", s.stride, s.stride == 1 ? 8 : 4, h->bf ? "true" : "false");
                 std::string lab;
                 for (int k = 0; k < g.n; ++k) {
                     const Op& ok = h->ops[g.op[k]];
@@ -1617,9 +1626,9 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                     const ConvSpec& sk = h->specs[dk.spec];
                     const Tensor& tk = h->tensors[ok.out];
                     lab += (k ? " + " : "") + sk.name;
-                    out->flops += 2.0 * n * lh[tk.level] * lw[tk.level] * sk.cout * sk.cin * 9.0;
+                    out->flops += 2.0 * n * lh[tk.level] * lw[tk.level] * sk.cout * sk.cin * (double)(sk.k * sk.k);
                     out->bytes += tbytes(ok.in) + tbytes(ok.out) + (ok.res >= 0 ? tbytes(ok.res) : 0.0) +
-                                  (double)(h->bf ? esa::packed_weight_bytes_bf(dk.coutp, dk.cinp, 3) : esa::packed_weight_bytes(dk.coutp, dk.cinp, 3));
+                                  (double)(h->bf ? esa::packed_weight_bytes_bf(dk.coutp, dk.cinp, sk.k) : esa::packed_weight_bytes(dk.coutp, dk.cinp, sk.k));
                 }
                 snprintf(out->label, sizeof out->label, "%s", lab.c_str());
                 break;
