@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 python3 bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err || exit 1
 cd $R
 bash tools/pmc_run.sh $TAG/pmc > $OUT/pmc.log 2>&1 || exit 1
 python3 tools/make_traffic_json.py $OUT/pmc $OUT/traffic.json > $OUT/traffic.log 2>&1
