@@ -47,6 +47,7 @@ _SIGS = {
     "esahrnet_handle_device": (C.c_int, [C.c_void_p]),
     "esahrnet_debug_devstate": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "esahrnet_debug_set_launch_limit": (C.c_int, [C.c_longlong]),
+    "esahrnet_debug_op_schedule": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "esahrnet_conv_count": (C.c_int, [C.c_void_p]),
     "esahrnet_conv_desc_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ConvDesc)]),
     "esahrnet_set_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -102,7 +102,12 @@ struct Op {
     int terms[4] = {-1, -1, -1, -1};
     int nterms = 0;
     bool relu = false;
-    int lane = 0;               // execution lane (stream): 0 = caller's stream, 1..3 = side streams
+    int lane = 0;               // execution lane (stream): 0 = caller's stream, 1..3 = side streams (schedule_waves)
+    int wave = 0;               // waves run one after another; inside a wave the lanes run beside each other
+    int wait0 = -1;             // side-lane launch: lane-0 op whose event it waits for first (-1: none)
+    bool wait_entry = false;    // side-lane launch: waits for the wave's entry event first
+    bool record = false;        // lane-0 op: an event is recorded behind it (a side lane forks from here)
+    unsigned join = 0;          // lane-0 launch: side lanes (bit l) lane 0 waits for first
     int aux[3] = {-1, -1, -1};  // CBAM ops: fc.0, fc.2, sa.conv1
     int c0 = 0;                 // channel offset inside `out` (OP_APPLY / OP_RESAMPLE / OP_ZERO)
     int nchan = 0;              // OP_ZERO: channels to clear;  OP_RESAMPLE/OP_APPLY/OP_MAPS: real channels
@@ -175,13 +180,16 @@ struct esahrnet_ctx {
     bool fuse_big = true;       // fused stem + fused head (ESAHRNET_UNFUSED=1 selects the op-by-op plan)
     bool head2_enabled = true;  // ESAHRNET_HEAD_V1=1 keeps the first-generation fused head for every shape
     int head2_op = -1;          // index of the OP_HEAD2 op, -1 if the plan has none
-    // optional multi-stream execution of independent branches (ESAHRNET_STREAMS=4 enables)
-    int nlanes = 1;             // measured on MI355X (round 1): 4 lanes are SLOWER (4.42 vs 4.03 ms), see DESIGN.md
+    // wave executor (schedule_waves): the launches of a wave that do not depend on each other run on up to four lanes
+    // (the caller's stream + three side streams), fork/join through the caller's stream at every wave boundary
+    int nlanes = 1;             // 1: everything on the caller's stream;  4: waves (ESAHRNET_STREAMS)
+    int nwaves = 1;
+    std::vector<int> wave_last;                       // per wave: index of its last op
+    std::vector<unsigned char> wave_mask;             // per wave: bit l set = lane l has work
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> op_event;                 // one per op, created at commit
-    hipEvent_t entry_event = nullptr, lane_end[3] = {nullptr, nullptr, nullptr};
-    std::vector<std::vector<int>> waits;              // per op: ops on OTHER lanes it must wait for (per-shape plan)
-    std::vector<char> needs_event;                    // per op: someone on another lane waits for it
+    std::vector<hipEvent_t> wave_entry;               // per wave: recorded on the caller's stream when the wave opens
+    std::vector<hipEvent_t> wave_end;                 // per op x side lane (Op::join) + the final join
+    std::vector<hipEvent_t> op_event;                 // per op with Op::record
     ShapePlan sp;
     int max_level = 0;
     std::vector<Multi> multis;
@@ -192,7 +200,6 @@ namespace {
 
 struct Builder {
     esahrnet_ctx& c;
-    int lane = 0;               // lane given to the ops being appended
     int jkey = -1;              // job key given to the next stride-1 convolutions (HRModule branches), -1: none
     int jkey2 = -1;             // job key given to the next stride-2 convolution (fuse-down chain link), -1: none
     explicit Builder(esahrnet_ctx& ctx) : c(ctx) {}
@@ -226,7 +233,7 @@ struct Builder {
         d.cinp = c.padc(d.c1 - d.c0); d.coutp = c.padc(s.cout);
         c.dconvs.push_back(d);
         Op o;
-        o.kind = OP_CONV; o.dconv = (int)c.dconvs.size() - 1; o.in = in; o.res = res; o.relu = relu; o.lane = lane;
+        o.kind = OP_CONV; o.dconv = (int)c.dconvs.size() - 1; o.in = in; o.res = res; o.relu = relu;
         if (jkey >= 0 && s.k == 3 && s.stride == 1) o.jkey = jkey++;
         if (jkey2 >= 0 && ((s.k == 3 && s.stride == 2) || s.k == 1)) o.jkey = jkey2;
         // ESAHRNET_TAP_ALL=1 (debugging): every convolution output becomes a named tap
@@ -239,7 +246,7 @@ struct Builder {
     }
     int fuse(const std::vector<int>& terms, int C, int level, bool relu, const std::string& tap = "") {
         Op o;
-        o.kind = OP_FUSE; o.nterms = (int)terms.size(); o.relu = relu; o.lane = lane;
+        o.kind = OP_FUSE; o.nterms = (int)terms.size(); o.relu = relu;
         o.out = tensor(C, level, tap);
         const int idx = (int)c.ops.size();
         c.tensors[o.out].def = idx;
@@ -254,7 +261,7 @@ struct Builder {
         return (int)c.aux.size() - 1;
     }
     int push(Op& o) {
-        o.lane = lane;
+       
         const int idx = (int)c.ops.size();
         if (o.out >= 0 && c.tensors[o.out].def < 0) c.tensors[o.out].def = idx;
         use(o.in, idx); use(o.res, idx);
@@ -313,7 +320,7 @@ struct Builder {
         const bool in_job = jkey >= 0 && !getenv("ESAHRNET_NO_JOBS");
         if (c.fuse_big && cin == cout && pad32(cin) == 32 && !getenv("ESAHRNET_NO_BBLOCK") && !in_job) {
             Op o;
-            o.kind = OP_BLOCK; o.in = x; o.relu = true; o.lane = lane;
+            o.kind = OP_BLOCK; o.in = x; o.relu = true;
             for (int k = 0; k < 2; ++k) {
                 DevConv d;
                 d.spec = k ? c2 : c1; d.c0 = 0; d.c1 = cin; d.use_bias = true; d.cinp = 32; d.coutp = 32;
@@ -339,7 +346,7 @@ struct Builder {
 // Post-pass over the op list: find the stride-2 3x3 convolutions that share their input and make each such group
 // consecutive (moving a member EARLIER is always legal: its only input is defined before the group's first member).
 void group_multihead(esahrnet_ctx& c) {
-    if (getenv("ESAHRNET_NO_MULTIHEAD") || c.nlanes > 1 || c.bf) return;
+    if (getenv("ESAHRNET_NO_MULTIHEAD") || c.bf) return;
     auto eligible = [&](const Op& o) {
         if (o.kind != OP_CONV || o.res >= 0 || o.alt != 0 || o.multi >= 0) return false;
         const DevConv& d = c.dconvs[o.dconv];
@@ -397,7 +404,7 @@ void group_multihead(esahrnet_ctx& c) {
 // branch by branch; here the convolutions of a module are put in depth-major order (stable, so every branch keeps its own
 // order) and the same-depth ones of up to three branches become a JobGroup.
 void group_jobs(esahrnet_ctx& c) {
-    if (getenv("ESAHRNET_NO_JOBS") || c.nlanes > 1) return;
+    if (getenv("ESAHRNET_NO_JOBS")) return;
     std::vector<Op> ops = c.ops;
     auto eligible = [&](const Op& o) {
         if (o.kind != OP_CONV || o.jkey < 0 || o.alt != 0 || o.multi >= 0) return false;
@@ -451,11 +458,109 @@ void group_jobs(esahrnet_ctx& c) {
         if (c.ops[k].multi >= 0) { Multi& m = c.multis[c.ops[k].multi]; m.op[c.ops[k].mpos] = (int)k; m.n = std::max(m.n, c.ops[k].mpos + 1); }
 }
 
+// Post-pass: lanes and waves.  Lane 0 is the caller's stream (the trunk), lanes 1..3 are side streams.  A launch unit (one
+// op, or the consecutive members of a job / multi-head group) is placed by what it depends on among the not yet joined
+// launches of the current wave — earlier writers of what it reads, earlier readers and writers of what it writes:
+//   lane 0 only, incl. its tail   -> lane 0: it continues the trunk;
+//   lane 0 only, not the tail     -> it forks onto the least loaded side lane behind the event of its latest lane-0
+//                                    dependency (or the wave's entry event): what lane 0 has queued since runs beside it;
+//   one side lane, not the trunk tail -> that side lane (behind the event of its latest lane-0 dependency, if newer);
+//   one side lane + the trunk tail, or two and more side lanes -> lane 0, which first waits for those side lanes (join).
+// A join that covers every side lane with work in flight ends the wave: all earlier launches are complete when the joining
+// unit starts.  plan_shape() keeps a tensor alive to the end of the wave of its last reader, so recycled scratch adds no
+// dependency inside a wave, and the schedule — true dependencies only — does not depend on the shape.
+// Side lanes only ever wait on events of lane 0, and lane 0 on theirs: ROCm 7.x overflows its stack in
+// hipStreamEndCapture when two non-origin streams of one capture have waited on each other (found with
+// tools/ubench/segv_bt.c); fork/join through the origin stream captures fine (tools/ubench/graph_branches.hip).
+void schedule_waves(esahrnet_ctx& c) {
+    const size_t nops = c.ops.size();
+    for (Op& o : c.ops) { o.lane = 0; o.wave = 0; o.wait0 = -1; o.wait_entry = false; o.record = false; o.join = 0; }
+    c.nwaves = 1;
+    if (c.nlanes > 1) {
+        std::vector<std::vector<int>> readers(c.tensors.size()), writers(c.tensors.size());
+        std::vector<int> unit_end(nops, 0);       // op -> last op of its launch unit
+        int wave = 0, wave_start = 0, tail0 = -1;
+        int load[4], waited0[4], tail[4], joined_tail[4], joined_op[4];
+        bool active[4];
+        auto reset = [&]() {
+            for (int l = 0; l < 4; ++l) { load[l] = 0; waited0[l] = -1; tail[l] = -1; joined_tail[l] = -1; joined_op[l] = -1; active[l] = false; }
+        };
+        reset();
+        for (size_t k = 0; k < nops;) {
+            size_t e = k + 1;
+            while (e < nops && ((c.ops[k].job >= 0 && c.ops[e].job == c.ops[k].job) ||
+                                (c.ops[k].multi >= 0 && c.ops[e].multi == c.ops[k].multi))) ++e;
+            unsigned side = 0;
+            int zmax = -1;
+            auto dep = [&](int d) {
+                if (d < wave_start || d >= (int)k) return;
+                const int l = c.ops[d].lane;
+                if (l == 0) zmax = std::max(zmax, unit_end[d]);
+                else if (d <= joined_tail[l]) zmax = std::max(zmax, joined_op[l]);      // already joined into the trunk
+                else side |= 1u << l;
+            };
+            for (size_t m = k; m < e; ++m) {
+                const Op& o = c.ops[m];
+                for (int t : {o.in, o.res, o.terms[0], o.terms[1], o.terms[2], o.terms[3]})
+                    if (t >= 0) for (int w : writers[t]) dep(w);
+                if (o.out >= 0) {
+                    for (int r : readers[o.out]) dep(r);
+                    for (int w : writers[o.out]) dep(w);
+                }
+            }
+            Op& lead = c.ops[k];
+            int lane = 0;
+            const int nside = __builtin_popcount(side);
+            if (nside >= 2 || (nside == 1 && zmax == tail0)) {
+                lead.join = side;
+                bool all = true;
+                for (int l = 1; l < 4; ++l) if (active[l] && !(side >> l & 1)) all = false;
+                if (all) {
+                    ++wave; wave_start = (int)k; tail0 = -1;
+                    reset();
+                } else {
+                    for (int l = 1; l < 4; ++l)
+                        if (side >> l & 1) { active[l] = false; joined_tail[l] = tail[l]; joined_op[l] = (int)e - 1; }
+                }
+            } else if (nside == 1) {
+                lane = __builtin_ctz(side);
+            } else if (zmax != tail0) {
+                lane = 1;
+                for (int l = 2; l < 4; ++l) if (load[l] < load[lane]) lane = l;
+            }
+            if (lane) {
+                if (zmax > waited0[lane]) { lead.wait0 = zmax; c.ops[zmax].record = true; waited0[lane] = zmax; }
+                else if (waited0[lane] < 0 && tail[lane] < 0) lead.wait_entry = true;
+                active[lane] = true;
+            }
+            ++load[lane];
+            for (size_t m = k; m < e; ++m) {
+                Op& o = c.ops[m];
+                o.lane = lane; o.wave = wave;
+                unit_end[m] = (int)e - 1;
+                for (int t : {o.in, o.res, o.terms[0], o.terms[1], o.terms[2], o.terms[3]}) if (t >= 0) readers[t].push_back((int)m);
+                if (o.out >= 0) writers[o.out].push_back((int)m);
+            }
+            tail[lane] = (int)e - 1;
+            if (!lane) tail0 = (int)e - 1;
+            k = e;
+        }
+        c.nwaves = wave + 1;
+    }
+    c.wave_last.assign(c.nwaves, 0);
+    c.wave_mask.assign(c.nwaves, 0);
+    for (size_t k = 0; k < nops; ++k) {
+        c.wave_last[c.ops[k].wave] = (int)k;
+        c.wave_mask[c.ops[k].wave] |= (unsigned char)(1u << c.ops[k].lane);
+    }
+}
+
 int build_plan_ops(esahrnet_ctx& c);
 int build_plan(esahrnet_ctx& c) {
     if (build_plan_ops(c)) return 1;
     group_multihead(c);
     group_jobs(c);
+    schedule_waves(c);
     return 0;
 }
 
@@ -524,7 +629,6 @@ int build_plan_ops(esahrnet_ctx& c) {
                 }
             } else {
                 int tt = ys.back();
-                B.lane = i;
                 const int nconv = i + 1 - (int)pre.size();
                 for (int j = 0; j < nconv; ++j) {
                     const std::string q = t + "." + std::to_string(i) + "." + std::to_string(j);
@@ -532,14 +636,12 @@ int build_plan_ops(esahrnet_ctx& c) {
                     tt = B.conv(B.spec(q + ".0", q + ".1", pre.back(), co, 3, 2, (int)pre.size() + j + 1, false, true), tt, -1, true);
                 }
                 xs.push_back(tt);
-                B.lane = 0;
             }
         }
         // ---- HighResolutionModule x NUM_MODULES (:105-249) ----
         for (int m = 0; m < g.modules[s - 1]; ++m) {
             const std::string p = "stage" + std::to_string(s) + "." + std::to_string(m);
             for (int b = 0; b < nb; ++b) {
-                B.lane = b;                  // the branches of a stage are independent chains
                 for (int k = 0; k < g.blocks[s - 1][b]; ++k) {
                     B.jkey = (((s << 4) | m) << 8) | (2 * k);       // conv1 / conv2 of block k take 2k / 2k + 1
                     xs[b] = B.basic_block(p + ".branches." + std::to_string(b) + "." + std::to_string(k),
@@ -553,11 +655,10 @@ int build_plan_ops(esahrnet_ctx& c) {
             std::vector<std::vector<int>> terms(nb, std::vector<int>(nb, -1));
             const int modkey = ((s << 4) | m) << 8;
             for (int i = 0; i < nb; ++i) {
-                B.lane = i;                  // everything that feeds output branch i runs on lane i
                 terms[i][i] = xs[i];
                 for (int j = i + 1; j < nb; ++j) {      // 1x1 + BN on the low-res grid; up-sampled inside fuse
                     const std::string q = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j);
-                    B.jkey2 = modkey | 200;             // all fuse-up 1x1 convolutions of the module are independent
+                    B.jkey2 = modkey | 100;             // all fuse-up 1x1 convolutions of the module are independent (before the chains)
                     terms[i][j] = B.conv(B.spec(q + ".0", q + ".1", cur[j], cur[i], 1, 1, 1 + j, false, false), xs[j], -1, false);
                     B.jkey2 = -1;
                 }
@@ -565,7 +666,6 @@ int build_plan_ops(esahrnet_ctx& c) {
             for (int k = 0; k + 1 < nb; ++k)            // link k of every chain of 3x3 s2 (:198-217) that has one
                 for (int i = k + 1; i < nb; ++i)
                     for (int j = 0; j + k < i; ++j) {
-                        B.lane = i;
                         const bool last = k == i - j - 1;
                         const std::string qq = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j) + "." + std::to_string(k);
                         const int sp_ = B.spec(qq + ".0", qq + ".1", cur[j], last ? cur[i] : cur[j], 3, 2, 1 + j + k + 1, false, !last);
@@ -575,13 +675,11 @@ int build_plan_ops(esahrnet_ctx& c) {
                     }
             std::vector<int> outs;
             for (int i = 0; i < nb; ++i) {
-                B.lane = i;
                 const bool final_module = m == g.modules[s - 1] - 1;
                 outs.push_back(B.fuse(terms[i], cur[i], 1 + i, true,
                                       final_module ? "stage" + std::to_string(s) + "." + std::to_string(i) : ""));
             }
             xs = outs;
-            B.lane = 0;
         }
         ys = xs;
         pre = cur;
@@ -645,12 +743,10 @@ int build_plan_ops(esahrnet_ctx& c) {
         for (int b = 1; b < 4; ++b) {
             const int save = c.specs[l0].level;
             c.specs[l0].level = 1 + b;
-            B.lane = b;
             o.terms[b - 1] = B.conv(l0, ys[b], -1, false, "", off, off + pre[b], false, true);
             c.ops.back().alt = o.alt;
             c.tensors[o.terms[b - 1]].alt = o.alt;
             dslice[b] = c.ops.back().dconv;
-            B.lane = 0;
             c.specs[l0].level = save;
             off += pre[b];
         }
@@ -669,9 +765,7 @@ int build_plan_ops(esahrnet_ctx& c) {
                 t.out = B.tensor(tot, 1 + b);
                 c.tensors[t.out].tlayout = true;
                 c.tensors[t.out].alt = 2;
-                B.lane = b;
                 B.push(t);
-                B.lane = 0;
                 tt[b] = t.out;
             }
             Op q; q.kind = OP_HEAD2; q.in = ys[0]; q.nterms = 3; q.alt = 2; q.dconv = dslice[1];
@@ -867,27 +961,7 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
             free_list.pop_back();
         }
     };
-    // ---- dependencies for multi-stream execution: RAW (producer -> consumer) plus, because buffers are
-    // recycled, WAR/WAW (every earlier accessor of a region -> the op that overwrites it) ----------------
     const size_t nops = c.ops.size();
-    auto inputs_of = [](const Op& o) {
-        std::vector<int> v;
-        if (o.in >= 0) v.push_back(o.in);
-        if (o.res >= 0) v.push_back(o.res);
-        for (int i = 0; i < o.nterms; ++i) if (o.terms[i] >= 0) v.push_back(o.terms[i]);
-        return v;
-    };
-    std::vector<std::vector<int>> accessors(c.tensors.size()), deps(nops);
-    std::vector<std::vector<int>> writers(c.tensors.size());
-    for (size_t k = 0; k < nops; ++k) {
-        for (int t : inputs_of(c.ops[k])) {
-            accessors[t].push_back((int)k);
-            for (int wr : writers[t]) deps[k].push_back(wr);         // every earlier writer (slices!)
-        }
-        if (c.ops[k].out >= 0) { accessors[c.ops[k].out].push_back((int)k); writers[c.ops[k].out].push_back((int)k); }
-    }
-    struct Retired { size_t off, len; int tensor; };
-    std::vector<Retired> retired;
     size_t high = 0;
     std::vector<char> allocated(c.tensors.size(), 0);
     for (size_t oi = 0; oi < nops; ++oi) {
@@ -898,15 +972,15 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
             const size_t len = bytes_of(c.tensors[o.out]);
             const size_t off = alloc(len);
             c.tensors[o.out].off = off;
-            for (const Retired& r : retired)
-                if (r.off < off + len && off < r.off + r.len)
-                    for (int a : accessors[r.tensor]) if (a < (int)oi) deps[oi].push_back(a);
             high = std::max(high, std::max(top, off + len));
         }
         // a job group runs as ONE launch: what one member reads last must not be handed to another member's output, so a
         // tensor whose last reader sits inside a group stays alive until the group's last member
+        // (and with lanes: until the last op of the wave, whose launches run concurrently)
         auto last_of = [&](const Tensor& t) {
-            if (t.last >= 0 && c.ops[t.last].job >= 0) {
+            if (t.last < 0) return t.last;
+            if (c.nlanes > 1) return c.wave_last[c.ops[t.last].wave];
+            if (c.ops[t.last].job >= 0) {
                 const JobGroup& g = c.jobs[c.ops[t.last].job];
                 return g.op[g.n - 1];
             }
@@ -915,29 +989,9 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
         if (!c.keep)
             for (size_t ti = 0; ti < c.tensors.size(); ++ti) {
                 Tensor& t = c.tensors[ti];
-                if (allocated[ti] && last_of(t) == (int)oi) {
-                    release(t.off, bytes_of(t));
-                    retired.push_back({t.off, bytes_of(t), (int)ti});
-                }
+                if (allocated[ti] && last_of(t) == (int)oi) release(t.off, bytes_of(t));
             }
         high = std::max(high, top);
-    }
-    // per op: the cross-lane waits that are not already implied by in-order execution of each lane
-    c.waits.assign(nops, {});
-    c.needs_event.assign(nops, 0);
-    int last_waited[4][4];
-    for (auto& row : last_waited) for (int& v : row) v = -1;
-    for (size_t k = 0; k < nops; ++k) {
-        const int L = c.ops[k].lane;
-        int latest[4] = {-1, -1, -1, -1};
-        for (int d : deps[k])
-            if (d >= 0 && c.ops[d].lane != L) latest[c.ops[d].lane] = std::max(latest[c.ops[d].lane], d);
-        for (int l2 = 0; l2 < 4; ++l2)
-            if (latest[l2] > last_waited[L][l2]) {
-                c.waits[k].push_back(latest[l2]);
-                c.needs_event[latest[l2]] = 1;
-                last_waited[L][l2] = latest[l2];
-            }
     }
     sp.bytes = high;
     c.sp = sp;
@@ -961,11 +1015,11 @@ void free_weights(esahrnet_ctx& c) {
         m.w = nullptr; m.bias = nullptr;
     }
     for (float** p : {&c.stemraw_w, &c.stemraw_b}) if (*p) { (void)hipFree(*p); *p = nullptr; }
-    for (hipEvent_t& e : c.op_event) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    c.op_event.clear();
-    if (c.entry_event) { (void)hipEventDestroy(c.entry_event); c.entry_event = nullptr; }
+    for (std::vector<hipEvent_t>* v : {&c.wave_entry, &c.wave_end, &c.op_event}) {
+        for (hipEvent_t& e : *v) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        v->clear();
+    }
     for (int i = 0; i < 3; ++i) {
-        if (c.lane_end[i]) { (void)hipEventDestroy(c.lane_end[i]); c.lane_end[i] = nullptr; }
         if (c.side[i]) { (void)hipStreamDestroy(c.side[i]); c.side[i] = nullptr; }
     }
     c.committed = false;
@@ -1037,6 +1091,13 @@ int esahrnet_debug_devstate(int* kernel_device_entries, int* devices) {
 
 int esahrnet_debug_set_launch_limit(long long bytes) {
     esa::set_stream_launch_limit(bytes);
+    return 0;
+}
+
+int esahrnet_debug_op_schedule(esahrnet_handle h, int index, int* wave, int* lane) {
+    if (!h || !wave || !lane || index < 0 || index >= (int)h->ops.size()) return fail("debug_op_schedule: bad argument");
+    *wave = h->ops[index].wave;
+    *lane = h->ops[index].lane;
     return 0;
 }
 
@@ -1205,14 +1266,18 @@ int esahrnet_commit(esahrnet_handle h) {
         std::copy(s3.b.begin(), s3.b.end(), b3.begin());
         if (upload(b0, reinterpret_cast<void**>(&h->head_b0)) || upload(b3, reinterpret_cast<void**>(&h->head_b3))) return 1;
     }
-    if (h->nlanes > 1) {     // side streams + events for the multi-stream executor
-        for (int i = 0; i < 3; ++i) {
-            HIP_OK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
-            HIP_OK(hipEventCreateWithFlags(&h->lane_end[i], hipEventDisableTiming));
-        }
-        HIP_OK(hipEventCreateWithFlags(&h->entry_event, hipEventDisableTiming));
+    if (h->nlanes > 1) {     // side streams + events for the wave executor
+        for (int i = 0; i < 3; ++i) HIP_OK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+        h->wave_entry.assign(h->nwaves, nullptr);
+        h->wave_end.assign((h->ops.size() + 1) * 3, nullptr);
+        for (hipEvent_t& e : h->wave_entry) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (size_t k = 0; k <= h->ops.size(); ++k)
+            for (int l = 1; l < 4; ++l)
+                if (k == h->ops.size() || (h->ops[k].join >> l & 1))
+                    HIP_OK(hipEventCreateWithFlags(&h->wave_end[k * 3 + l - 1], hipEventDisableTiming));
         h->op_event.assign(h->ops.size(), nullptr);
-        for (hipEvent_t& e : h->op_event) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (size_t k = 0; k < h->ops.size(); ++k)
+            if (h->ops[k].record) HIP_OK(hipEventCreateWithFlags(&h->op_event[k], hipEventDisableTiming));
     }
     h->committed = true;
     return 0;
@@ -1245,34 +1310,41 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
     auto T = [&](int t) { return ws + h->tensors[t].off; };
     int op_index = 0;
     if (events && hipEventRecord(events[0], stream) != hipSuccess) return fail("forward: hipEventRecord failed");
-    // multi-stream executor: lane 0 is the caller's stream; independent branch chains run on side
-    // streams, ordered by per-op events (fork/join pattern, also valid under stream capture).  The timed
-    // and the keep-intermediates modes stay on one stream.
-    bool multi = !events && !h->keep && h->nlanes > 1 && h->side[0] != nullptr;
+    // wave executor: lane 0 is the caller's stream; the other lanes of a wave are side streams that fork from and join
+    // into it (also valid under stream capture: the graph gets parallel branches).  The timed and the
+    // keep-intermediates modes stay on one stream.
+    const bool multi = !events && !h->keep && h->nlanes > 1 && h->side[0] != nullptr;
     const hipStream_t caller = stream;
-    if (multi) {
-        // ROCm 7.0/7.2: pulling side streams into a stream capture crashes inside the runtime, so a
-        // forward that is being captured into a graph stays on the capturing stream
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) multi = false;
-    }
     bool lane_used[4] = {true, false, false, false};
-    if (multi) HIP_OK(hipEventRecord(h->entry_event, caller));
+    int cur_wave = -1;
+    auto join = [&](size_t slot, unsigned lanes) -> int {      // the caller's stream continues behind those side lanes
+        for (int l = 1; l < 4; ++l)
+            if ((lanes >> l & 1) && lane_used[l]) {
+                hipEvent_t e = h->wave_end[slot * 3 + l - 1];
+                if (hipEventRecord(e, h->side[l - 1]) != hipSuccess || hipStreamWaitEvent(caller, e, 0) != hipSuccess) return 1;
+                lane_used[l] = false;
+            }
+        return 0;
+    };
     const int active_alt = sp.head2 ? 2 : 1;
     for (const Op& o : h->ops) {
         int rc = 0;
+        if (multi) {
+            if (o.join && join((size_t)op_index, o.join)) return fail("forward: joining side lanes failed");
+            if (o.wave != cur_wave) {
+                cur_wave = o.wave;
+                if (h->wave_mask[cur_wave] & ~1u) HIP_OK(hipEventRecord(h->wave_entry[cur_wave], caller));
+            }
+            stream = o.lane == 0 ? caller : h->side[o.lane - 1];
+            lane_used[o.lane] = true;
+            if (o.wait_entry) HIP_OK(hipStreamWaitEvent(stream, h->wave_entry[cur_wave], 0));
+            if (o.wait0 >= 0) HIP_OK(hipStreamWaitEvent(stream, h->op_event[o.wait0], 0));
+        }
         if (o.alt != 0 && o.alt != active_alt) {         // the head alternative not used at this shape
+            if (multi && o.record) HIP_OK(hipEventRecord(h->op_event[op_index], caller));
             ++op_index;
             if (events && hipEventRecord(events[op_index], stream) != hipSuccess) return fail("forward: hipEventRecord failed");
             continue;
-        }
-        if (multi) {
-            stream = o.lane == 0 ? caller : h->side[o.lane - 1];
-            if (!lane_used[o.lane]) {
-                HIP_OK(hipStreamWaitEvent(stream, h->entry_event, 0));
-                lane_used[o.lane] = true;
-            }
-            for (int d : h->waits[op_index]) HIP_OK(hipStreamWaitEvent(stream, h->op_event[d], 0));
         }
         switch (o.kind) {
             case OP_STEM: {
@@ -1498,16 +1570,11 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
             }
         }
         if (rc) return fail("forward: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        if (multi && h->needs_event[op_index]) HIP_OK(hipEventRecord(h->op_event[op_index], stream));
+        if (multi && o.record) HIP_OK(hipEventRecord(h->op_event[op_index], caller));
         ++op_index;
         if (events && hipEventRecord(events[op_index], stream) != hipSuccess) return fail("forward: hipEventRecord failed");
     }
-    if (multi)               // join: the caller's stream continues only after every side lane has drained
-        for (int l = 1; l < 4; ++l)
-            if (lane_used[l]) {
-                HIP_OK(hipEventRecord(h->lane_end[l - 1], h->side[l - 1]));
-                HIP_OK(hipStreamWaitEvent(caller, h->lane_end[l - 1], 0));
-            }
+    if (multi && join(h->ops.size(), 0xeu)) return fail("forward: joining the side lanes failed");
     return 0;
 }
 

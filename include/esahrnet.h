@@ -192,6 +192,9 @@ int esahrnet_debug_devstate(int* kernel_device_entries, int* devices);
 /* Bytes one launch of the stream convolution kernels may address (default and maximum 2^31 - 1); batches beyond it
  * are cut into image ranges on the host.  Lowered by the tests to exercise the cut at small sizes; 0 restores. */
 int esahrnet_debug_set_launch_limit(long long bytes);
+/* Where launch `index` (0 .. esahrnet_launch_count-1) sits in the wave schedule: launches of one wave on different
+ * lanes run concurrently (lane 0 = the caller's stream), waves one after another.  All zero on a one-lane handle. */
+int esahrnet_debug_op_schedule(esahrnet_handle h, int index, int* wave, int* lane);
 
 #ifdef __cplusplus
 }

@@ -228,19 +228,39 @@ def test_odd_geometry_head_carries_lo_weights(env):
 
 
 def test_multistream_executor_matches_single_stream(env, monkeypatch):
-    """ESAHRNET_STREAMS=4 runs independent branch chains on side streams ordered by per-op events
-    (RAW + buffer-recycling WAR/WAW dependencies).  Must be bit-identical to the single-stream run."""
-    net1, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 5)
-    x = env["synth"].make_crops(8, 1, 128, 128, seed=5).cuda()
-    with torch.no_grad():
-        y1 = net1(x).clone()
-    monkeypatch.setenv("ESAHRNET_STREAMS", "4")
-    net4, _ = _build(env, "seg_hrnet2", (32, 64, 128, 256), 5)
-    with torch.no_grad():
-        ys = [net4(x).clone() for _ in range(5)]
-    torch.cuda.synchronize()
-    for y in ys:
-        assert torch.equal(y, y1)
+    """ESAHRNET_STREAMS=4: the launches a wave schedule finds independent run on side streams that fork from and join
+    into the caller's stream (plan.hip schedule_waves).  Must be bit-identical to the one-stream run, eagerly and
+    captured into a HIP graph (the capture gets parallel branches), at two shapes, for both variants."""
+    for variant, widths, shape in (("seg_hrnet2", (32, 64, 128, 256), (8, 1, 128, 128)),
+                                   ("seg_hrnet2", (32, 64, 128, 256), (3, 1, 96, 160)),
+                                   ("seg_hrnet3", (32, 64, 128, 256), (2, 1, 128, 128))):
+        monkeypatch.delenv("ESAHRNET_STREAMS", raising=False)
+        net1, sd = _build(env, variant, widths, 5)
+        x = env["synth"].make_crops(*shape, seed=5).cuda()
+        with torch.no_grad():
+            y1 = net1(x).clone()
+        monkeypatch.setenv("ESAHRNET_STREAMS", "4")
+        net4, _ = _build(env, variant, widths, 5)
+        with torch.no_grad():
+            ys = [net4(x).clone() for _ in range(4)]
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                yg = net4(x)
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+        for y in ys + [yg]:
+            assert torch.equal(y, y1), (variant, shape)
+    # the schedule really has side lanes (else the test above proves nothing)
+    import ctypes as C
+    from esa_pose_estimation_amd import _lib
+    h = net4._rt._handle_for(net4, x.device)
+    w, l, lanes = C.c_int(), C.c_int(), set()
+    for i in range(_lib.lib().esahrnet_launch_count(h)):
+        _lib.check(_lib.lib().esahrnet_debug_op_schedule(h, i, C.byref(w), C.byref(l)))
+        lanes.add(l.value)
+    assert len(lanes) >= 2 and w.value >= 1, (lanes, w.value)
 
 
 def test_intermediate_tensors_match_oracle(env):
