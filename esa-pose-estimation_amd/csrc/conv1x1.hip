@@ -9,6 +9,8 @@
 // LDS one 32-cout chunk at a time (A operand: rows = output channels), the next chunk's fragments in
 // flight while the current one is consumed.  D[cout][pixel] leaves 4 consecutive channels of a pixel
 // per lane: 16-byte SB chunk stores (sb.h).
+#include <algorithm>
+
 #include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
@@ -20,7 +22,7 @@ namespace {
 // two K-steps of a block (sb.h), 2 MFMAs instead of 3, and the epilogue packs 4 channels into 8 bytes.
 template <int NCH, bool BF>
 __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long long ntiles, const int tiles_per_row,
-                                             const int bid, const int G) {
+                                             const int bid, const int G, const int split = 0, const int nsplit = 1) {
     constexpr int WFR = 4 * NCH;                   // 1-KB weight fragments per 32-cout chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -31,7 +33,10 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
     const long long row = tile / tiles_per_row;                 // n*H + y
     const int col = k * 16 + i;
     const bool valid = live && col < p.W;
-    const int nchunks = p.Coutp >> 5;
+    // very wide outputs (the nine-tap products of head_gather.hip: 135 chunks) are cut into `nsplit` ranges of 32-cout
+    // chunks, one workgroup each: more workgroups than CUs on a 16x16 grid, and a shorter serial chunk loop
+    const int per = ((p.Coutp >> 5) + nsplit - 1) / nsplit;
+    const int c_begin = split * per, nchunks = min(c_begin + per, p.Coutp >> 5);
 
     bf16x8 xh[NCH], xl[NCH];
 #pragma unroll
@@ -59,12 +64,13 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
         _Pragma("unroll") for (int it = 0; it < NCH; ++it)                                    \
             *reinterpret_cast<u32x4*>(smem + (BUF) * (WFR * 1024) + (it * 256 + tid) * 16) = wreg[it]; \
     }
-    C1_PREFETCH(0)
+    if (c_begin >= nchunks) return;
+    C1_PREFETCH(c_begin)
     C1_COMMIT(0)
     __syncthreads();
     char* orow = p.y + ((size_t)row * p.W + col) * (size_t)(p.Coutp * (BF ? 2 : 4));
-    for (int cc = 0; cc < nchunks; ++cc) {
-        const int buf = cc & 1;
+    for (int cc = c_begin; cc < nchunks; ++cc) {
+        const int buf = (cc - c_begin) & 1;
         if (cc + 1 < nchunks) C1_PREFETCH(cc + 1)
         const char* wb = smem + buf * (WFR * 1024) + lane * 16;
 #pragma unroll
@@ -92,6 +98,8 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
             }
             if (BF) {
                 if (valid) *reinterpret_cast<uint2*>(orow + co * 2) = pack4_bf16(v);
+            } else if (p.out_f32) {         // plain f32 NHWC (same pixel pitch): the nine-tap products read by head_gather.hip
+                if (valid) *reinterpret_cast<float4*>(orow + co * 4) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 hi, lo;
                 split4(v, hi, lo);
@@ -110,7 +118,7 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
 
 template <int NCH, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long ntiles, int tiles_per_row) {
-    conv1x1_body<NCH, BF>(p, ntiles, tiles_per_row, (int)blockIdx.x, (int)gridDim.x);
+    conv1x1_body<NCH, BF>(p, ntiles, tiles_per_row, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // Several independent 1x1 convolutions in one launch (the fuse-up convolutions of an HRModule, models/seg_hrnet.py:
@@ -147,7 +155,9 @@ int launch_conv1x1_n(const ConvParams& p, hipStream_t stream) {
     const long long ntiles = (long long)p.N * p.H * tiles_per_row;
     const long long nblk = (ntiles + 3) / 4;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, p, ntiles, tiles_per_row);
+    int nsplit = 1;
+    if ((p.Coutp >> 5) >= 32) nsplit = (int)std::min<long long>(8, std::max<long long>(1, (4LL * device_cus() + nblk - 1) / nblk));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)nsplit), dim3(256), lds, stream, p, ntiles, tiles_per_row);
     return (int)hipGetLastError();
 }
 
@@ -162,7 +172,7 @@ bool conv1x1_supported(const ConvParams& p) {
                (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12);
     }
     const int n = p.Cinp / 32;
-    return (p.Cinp % 32) == 0 && (p.Coutp % 32) == 0 && !p.res && !p.out_f32 && p.H == p.OH && p.W == p.OW &&
+    return (p.Cinp % 32) == 0 && (p.Coutp % 32) == 0 && !p.res && p.H == p.OH && p.W == p.OW &&
            (n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12);
 }
 
@@ -195,7 +205,7 @@ bool conv1x1_jobs_supported(const ConvParams* ps, int n) {
     if (n < 2 || n > C1_MAXJOBS) return false;
     for (int j = 0; j < n; ++j) {
         const int nch = ps[j].Cinp / 32;
-        if (ps[j].bf || !conv1x1_supported(ps[j]) || (nch != 2 && nch != 4 && nch != 8)) return false;
+        if (ps[j].bf || ps[j].out_f32 || !conv1x1_supported(ps[j]) || (nch != 2 && nch != 4 && nch != 8)) return false;
     }
     return true;
 }

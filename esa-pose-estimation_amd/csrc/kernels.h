@@ -206,6 +206,17 @@ struct ResampleParams {
 int launch_resample_slice(const ResampleParams& p, hipStream_t s);
 int launch_zero_slice(char* y, long long npix, int y_pix_bytes, int c0, int nchan, hipStream_t s);
 
+// ---- seg_hrnet3 head: low-resolution branches' share of last_layer[0] (head_gather.hip) ----
+struct GatherParams {
+    const char* z[2];   // SB [N][h][w][zpix / 4]: the nine 1x1 products per output channel, channel (cout/8)*72 + tap*8 + cout%8
+    char* y;            // SB [N][H][W][Cp]
+    int N, H, W, C, Cp;                 // C real output channels, Cp padded (the padding is written as zeros)
+    int h[2], w[2], zpix[2];
+    int R[2], Cc[2], ngroups, nreal, gpw;      // filled by the launcher
+};
+bool head_gather_supported(int H, int W, const int* h, const int* w, int Cp);
+int launch_head_gather(GatherParams p, hipStream_t stream);
+
 // ---- arg-max + log-quadratic refine (keypoints.hip) ----------------------------------------
 // idx_out: optional int32 [planes], the flat index (row * W + column) of the arg-max
 int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, int* idx_out, hipStream_t stream);

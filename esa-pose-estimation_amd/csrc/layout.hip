@@ -55,6 +55,25 @@ __global__ __launch_bounds__(256) void sb_to_nchw_kernel(const char* x, int N, i
     y[idx] = bf16_bits_to_f32(hi) + bf16_bits_to_f32(lo);
 }
 
+// SB -> NCHW for the network output: thread = (pixel, 8-channel group), group fastest, so a wave reads whole pixels
+// (contiguous 32-byte groups) and writes 64-byte runs of 16 consecutive pixels into each of its planes.  The element-wise
+// kernel above (thread = output element) touches a different 128-byte line per lane for two bytes: 0.9 TB/s.
+__global__ __launch_bounds__(256) void sb_to_nchw_groups_kernel(const char* x, int C, long long hw, int Cp, float* y, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int G = (C + 7) >> 3;
+    const int g = (int)(idx % G);
+    const long long pix = idx / G;                  // n * hw + s
+    const long long n = pix / hw, sp = pix - n * hw;
+    const char* a = x + (size_t)pix * (size_t)(Cp * 4) + g * 32;
+    float v[8];
+    join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+    float* o = y + ((size_t)n * C + (size_t)g * 8) * (size_t)hw + sp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (g * 8 + j < C) o[(size_t)j * hw] = v[j];
+}
+
 }  // namespace
 
 int launch_nchw_to_sb(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s) {
@@ -74,10 +93,10 @@ int launch_nchw_to_bf(const float* x, int N, int C, int H, int W, char* y, int C
 }
 
 int launch_sb_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s) {
-    const long long total = (long long)N * C * H * W;
+    const long long total = (long long)N * H * W * ((C + 7) >> 3);
     const long long nblk = (total + 255) / 256;
-    if (nblk <= 0 || nblk > 0x7fffffffLL || C > Cp) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(sb_to_nchw_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, x, N, C, H, W, Cp, y, total);
+    if (nblk <= 0 || nblk > 0x7fffffffLL || C > Cp || (Cp & 7)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sb_to_nchw_groups_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, C, (long long)H * W, Cp, y, total);
     return (int)hipGetLastError();
 }
 

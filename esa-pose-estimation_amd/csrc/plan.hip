@@ -59,6 +59,9 @@ struct ConvSpec {               // one Conv2d of the reference module tree
     bool has_bias, relu;
     std::vector<float> w, b;    // folded weights as handed over by the host
     bool set = false;
+    // derived spec (not visible to the host; filled at commit): the nine taps of input channels [pc0, pc1) of 3x3 spec `parent`
+    // as ONE 1x1 convolution with 9 * cout outputs, output channel (co / 8) * 72 + tap * 8 + co % 8 (head_gather.hip)
+    int parent = -1, pc0 = 0, pc1 = 0;
 };
 
 struct DevConv {                // one MFMA convolution launch (a ConvSpec or a cin-slice of one)
@@ -74,7 +77,7 @@ struct DevConv {                // one MFMA convolution launch (a ConvSpec or a 
 
 enum OpKind { OP_STEM, OP_STEMF, OP_CONV, OP_BLOCK, OP_FUSE, OP_HEAD, OP_HEADT, OP_HEAD2, OP_FINAL, OP_HEADBF,
               // seg_hrnet3 (CBAM) variant only:
-              OP_STEMRAW, OP_POOL, OP_MLP, OP_MAPS, OP_APPLY, OP_RESAMPLE, OP_ZERO, OP_TONCHW };
+              OP_STEMRAW, OP_POOL, OP_MLP, OP_MAPS, OP_APPLY, OP_RESAMPLE, OP_ZERO, OP_TONCHW, OP_GATHER };
 
 struct AuxSpec {                // a non-conv parameter tensor (CBAM weights)
     std::string name;
@@ -192,6 +195,7 @@ struct esahrnet_ctx {
     std::vector<hipEvent_t> op_event;                 // per op with Op::record
     ShapePlan sp;
     int max_level = 0;
+    int nhost_specs = -1;       // specs [nhost_specs, end) are derived (ConvSpec::parent); -1: none
     std::vector<Multi> multis;
     std::vector<JobGroup> jobs;
 };
@@ -213,6 +217,14 @@ struct Builder {
         c.spec_by_name[name] = (int)c.specs.size() - 1;
         c.max_level = std::max(c.max_level, level);
         return (int)c.specs.size() - 1;
+    }
+    int taps_spec(int parent, int c0, int c1, int level) {
+        const std::string name = c.specs[parent].name + "#taps[" + std::to_string(c0) + ":" + std::to_string(c1) + "]";
+        const int cout9 = 9 * ((c.specs[parent].cout + 7) & ~7);
+        const int sp = spec(name, "", c1 - c0, cout9, 1, 1, level, false, false);
+        c.specs[sp].parent = parent; c.specs[sp].pc0 = c0; c.specs[sp].pc1 = c1;
+        if (c.nhost_specs < 0) c.nhost_specs = sp;
+        return sp;
     }
     int tensor(int C, int level, const std::string& tap = "") {
         Tensor t;
@@ -261,7 +273,6 @@ struct Builder {
         return (int)c.aux.size() - 1;
     }
     int push(Op& o) {
-       
         const int idx = (int)c.ops.size();
         if (o.out >= 0 && c.tensors[o.out].def < 0) c.tensors[o.out].def = idx;
         use(o.in, idx); use(o.res, idx);
@@ -696,18 +707,46 @@ int build_plan_ops(esahrnet_ctx& c) {
         const int l0 = B.spec("last_layer.0", "last_layer.1", tot, tot, 3, 1, 1, true, true);
         const int l3 = B.spec("last_layer.3", "last_layer.4", tot, K, 1, 1, 1, true, true);
         c.spec_final = B.spec("output_layer.0", "", K + sw, K, 3, 1, 0, true, false);
-        const int cat = B.tensor(tot, 1, "head_cat");
-        int off = 0;
-        for (size_t b = 0; b < ys.size(); ++b) {
-            Op o; o.kind = OP_RESAMPLE; o.in = ys[b]; o.out = cat; o.c0 = off; o.nchan = pre[b]; o.align = 0;
-            B.push(o);
-            off += pre[b];
+        int h0;
+        if (ys.size() == 4 && !c.bf && !getenv("ESAHRNET_HEAD3_DIRECT")) {
+            // last_layer[0] by linearity (head_gather.hip): branches 2, 3 as nine 1x1 products on their own grids + a gather,
+            // branch 0 and the up-sampled branch 1 as a direct 3x3 that takes the gather's result as its residual
+            const int cd = pre[0] + pre[1];
+            const int cat = B.tensor(cd, 1, "head_cat");
+            int off = 0;
+            for (int b = 0; b < 2; ++b) {
+                Op o; o.kind = OP_RESAMPLE; o.in = ys[b]; o.out = cat; o.c0 = off; o.nchan = pre[b]; o.align = 0;
+                B.push(o);
+                off += pre[b];
+            }
+            if (pad32(cd) > ((cd + 7) & ~7)) {
+                Op o; o.kind = OP_ZERO; o.out = cat; o.terms[0] = cat; o.c0 = (cd + 7) & ~7; o.nchan = pad32(cd) - ((cd + 7) & ~7);
+                B.push(o);
+            }
+            int z[2];
+            for (int b = 2; b < 4; ++b) {
+                const int zs = B.taps_spec(l0, off, off + pre[b], 1 + b);
+                z[b - 2] = B.conv(zs, ys[b], -1, false, "", 0, -1, false, true);      // plain f32: the gather needs no join
+                off += pre[b];
+            }
+            Op gop; gop.kind = OP_GATHER; gop.in = z[0]; gop.nterms = 1; gop.terms[0] = z[1];
+            gop.out = B.tensor(tot, 1, "head_gather");
+            B.push(gop);
+            h0 = B.conv(l0, cat, gop.out, true, "head0", 0, cd);
+        } else {
+            const int cat = B.tensor(tot, 1, "head_cat");
+            int off = 0;
+            for (size_t b = 0; b < ys.size(); ++b) {
+                Op o; o.kind = OP_RESAMPLE; o.in = ys[b]; o.out = cat; o.c0 = off; o.nchan = pre[b]; o.align = 0;
+                B.push(o);
+                off += pre[b];
+            }
+            if (pad32(tot) > ((tot + 7) & ~7)) {
+                Op o; o.kind = OP_ZERO; o.out = cat; o.terms[0] = cat; o.c0 = (tot + 7) & ~7; o.nchan = pad32(tot) - ((tot + 7) & ~7);
+                B.push(o);
+            }
+            h0 = B.conv(l0, cat, -1, true, "head0");
         }
-        if (pad32(tot) > ((tot + 7) & ~7)) {
-            Op o; o.kind = OP_ZERO; o.out = cat; o.terms[0] = cat; o.c0 = (tot + 7) & ~7; o.nchan = pad32(tot) - ((tot + 7) & ~7);
-            B.push(o);
-        }
-        const int h0 = B.conv(l0, cat, -1, true, "head0");
         const int h3 = B.conv(l3, h0, -1, true, "head3");
         const int cat2 = B.tensor(sw + K, 0, "head_cat2");
         B.cbam("", stem_raw, sw, -1, false, cat2, 0);
@@ -1101,10 +1140,12 @@ int esahrnet_debug_op_schedule(esahrnet_handle h, int index, int* wave, int* lan
     return 0;
 }
 
-int esahrnet_conv_count(esahrnet_handle h) { return h ? (int)h->specs.size() : -1; }
+// the convolutions the host fills: derived specs (ConvSpec::parent) sit behind them and are filled at commit
+static int host_specs(const esahrnet_ctx* h) { return h->nhost_specs >= 0 ? h->nhost_specs : (int)h->specs.size(); }
+int esahrnet_conv_count(esahrnet_handle h) { return h ? host_specs(h) : -1; }
 
 int esahrnet_conv_desc_get(esahrnet_handle h, int i, esahrnet_conv_desc* out) {
-    if (!h || !out || i < 0 || i >= (int)h->specs.size()) return fail("conv_desc_get: bad index %d", i);
+    if (!h || !out || i < 0 || i >= host_specs(h)) return fail("conv_desc_get: bad index %d", i);
     const ConvSpec& s = h->specs[i];
     memset(out, 0, sizeof *out);
     snprintf(out->name, sizeof out->name, "%s", s.name.c_str());
@@ -1115,7 +1156,7 @@ int esahrnet_conv_desc_get(esahrnet_handle h, int i, esahrnet_conv_desc* out) {
 }
 
 int esahrnet_set_conv(esahrnet_handle h, int i, const float* w, const float* b) {
-    if (!h || !w || !b || i < 0 || i >= (int)h->specs.size()) return fail("set_conv: bad argument (index %d)", i);
+    if (!h || !w || !b || i < 0 || i >= host_specs(h)) return fail("set_conv: bad argument (index %d)", i);
     ConvSpec& s = h->specs[i];
     const size_t nw = (size_t)s.cout * s.cin * s.k * s.k;
     s.w.assign(w, w + nw);
@@ -1148,6 +1189,18 @@ int esahrnet_set_aux(esahrnet_handle h, int i, const float* w) {
 
 int esahrnet_commit(esahrnet_handle h) {
     if (!h) return fail("commit: null handle");
+    for (ConvSpec& s : h->specs) {
+        if (s.parent < 0) continue;
+        const ConvSpec& ps = h->specs[s.parent];
+        if (!ps.set) return fail("commit: weights of '%s' were never set", ps.name.c_str());
+        s.w.assign((size_t)s.cout * s.cin, 0.f);
+        s.b.assign(s.cout, 0.f);
+        for (int co = 0; co < ps.cout; ++co)
+            for (int t = 0; t < 9; ++t)
+                for (int ci = 0; ci < s.cin; ++ci)
+                    s.w[(size_t)((co >> 3) * 72 + t * 8 + (co & 7)) * s.cin + ci] = ps.w[((size_t)co * ps.cin + s.pc0 + ci) * 9 + t];
+        s.set = true;
+    }
     for (const ConvSpec& s : h->specs)
         if (!s.set) return fail("commit: weights of '%s' were never set", s.name.c_str());
     for (const AuxSpec& a : h->aux)
@@ -1403,6 +1456,18 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 p.h = sp.lh[ti.level]; p.w = sp.lw[ti.level]; p.H = sp.lh[to.level]; p.W = sp.lw[to.level];
                 p.C = o.nchan; p.Cp_src = ti.Cp; p.y_pix_bytes = to.Cp * 4; p.y_c0 = o.c0; p.align = o.align;
                 rc = esa::launch_resample_slice(p, stream);
+                break;
+            }
+            case OP_GATHER: {
+                const Tensor& to = h->tensors[o.out];
+                esa::GatherParams p{};
+                const int zt[2] = {o.in, o.terms[0]};
+                for (int b = 0; b < 2; ++b) {
+                    const Tensor& tz = h->tensors[zt[b]];
+                    p.z[b] = T(zt[b]); p.h[b] = sp.lh[tz.level]; p.w[b] = sp.lw[tz.level]; p.zpix[b] = tz.Cp * 4;
+                }
+                p.y = T(o.out); p.N = n; p.H = sp.lh[to.level]; p.W = sp.lw[to.level]; p.C = to.C; p.Cp = to.Cp;
+                rc = esa::launch_head_gather(p, stream);
                 break;
             }
             case OP_ZERO: {
@@ -1779,12 +1844,13 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             break;
         }
         case OP_STEMRAW: case OP_POOL: case OP_MLP: case OP_MAPS: case OP_APPLY: case OP_RESAMPLE: case OP_ZERO:
-        case OP_TONCHW: {
+        case OP_TONCHW: case OP_GATHER: {
             static const char* names[] = {"stem_kernel(raw)", "pool_partial", "ca_mlp", "cbam_maps", "cbam_apply",
-                                          "resample_slice", "zero_slice", "sb_to_nchw"};
+                                          "resample_slice", "zero_slice", "sb_to_nchw", "head_gather"};
             snprintf(out->kernel, sizeof out->kernel, "%s", names[o.kind - OP_STEMRAW]);
             snprintf(out->label, sizeof out->label, "seg_hrnet3");
             out->bytes = (o.in >= 0 ? tbytes(o.in) : 0.0) + (o.out >= 0 ? tbytes(o.out) : 0.0);
+            if (o.kind == OP_GATHER) out->bytes += tbytes(o.terms[0]);
             break;
         }
         case OP_FINAL: {
@@ -1829,8 +1895,8 @@ int esahrnet_flops_per_crop(esahrnet_handle h, int height, int width, double* fl
     std::vector<int> lh, lw;
     level_dims(*h, height, width, lh, lw);
     double f = 0;
-    for (const ConvSpec& s : h->specs)
-        f += 2.0 * lh[s.level] * lw[s.level] * s.cout * s.cin * s.k * s.k;
+    for (const ConvSpec& s : h->specs)        // the reference's direct form: derived specs restate work already counted
+        if (s.parent < 0) f += 2.0 * lh[s.level] * lw[s.level] * s.cout * s.cin * s.k * s.k;
     *flops = f;
     return 0;
 }

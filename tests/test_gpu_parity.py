@@ -480,6 +480,35 @@ def test_hrnet3_intermediates_match_oracle(env):
     assert (taps["heatmaps"].cpu() - out_ref).abs().max().item() <= GUARD
 
 
+@pytest.mark.parametrize("hw", [(70, 50), (16, 16), (36, 132), (128, 128)])
+def test_hrnet3_head_by_linearity_matches_oracle_and_direct_form(env, monkeypatch, hw):
+    """seg_hrnet3 last_layer[0] (3x3 over the concatenated, up-sampled branches, seg_hrnet3.py:506-515) runs as
+    nine 1x1 products on the grids of branches 2 and 3 + head_gather.hip + a direct 3x3 over [branch 0 | up(branch 1)].
+    Odd level sizes (70x50 -> 35x25, 18x13, 9x7, 5x4: non-integer up-sampling ratios, windows that differ per tile), the
+    smallest legal crop, a wide one and the square case: against the oracle, and against the direct 480-channel form
+    of the same handle family (ESAHRNET_HEAD3_DIRECT=1), which must agree to rounding."""
+    widths = (16, 32, 64, 128)
+    x = env["synth"].make_crops(2, 1, hw[0], hw[1], seed=41)
+    monkeypatch.delenv("ESAHRNET_HEAD3_DIRECT", raising=False)
+    net, sd = _build(env, "seg_hrnet3", widths, 41)
+    cfg = env["hrnet_ref"].default_cfg(1, 30, widths=widths, variant=1)
+    taps_ref = {}
+    with torch.no_grad():
+        out_ref = env["hrnet_ref"].forward(sd, cfg, x, taps_ref)
+        y, ops = net.forward_timed(x.cuda())
+        taps = net.taps(x.cuda())
+    assert "head_gather" in {o["kernel"] for o in ops}
+    assert (y.cpu() - out_ref).abs().max().item() <= GUARD
+    scale = max(1.0, taps_ref["head0"].abs().max().item())
+    assert (taps["head0"].cpu() - taps_ref["head0"]).abs().max().item() <= 3e-5 * scale
+    monkeypatch.setenv("ESAHRNET_HEAD3_DIRECT", "1")
+    net_d, _ = _build(env, "seg_hrnet3", widths, 41)
+    with torch.no_grad():
+        y_d, ops_d = net_d.forward_timed(x.cuda())
+    assert "head_gather" not in {o["kernel"] for o in ops_d}
+    assert (y_d - y).abs().max().item() <= 2e-5
+
+
 # ------------------------------------------------------------------------------------- boundary (round 2)
 def test_dataparallel_wrapper_and_replicas(env):
     """val.py:380-388: `net = DataParallel(NetWrapper(net)).cuda()`, weights loaded through `net.module.net`,
