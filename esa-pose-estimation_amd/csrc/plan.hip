@@ -299,11 +299,14 @@ struct Builder {
         Tensor mt; mt.C = 2; mt.Cp = 2; mt.level = level;
         c.tensors.push_back(mt);
         const int maps = (int)c.tensors.size() - 1;
-        { Op o; o.kind = OP_POOL; o.in = x; o.out = partial; push(o); }
-        { Op o; o.kind = OP_MLP; o.in = partial; o.out = cav; o.aux[0] = a0; o.aux[1] = a1; o.nchan = C; o.terms[0] = x; push(o); }
-        { Op o; o.kind = OP_MAPS; o.in = x; o.terms[1] = cav; o.out = maps; o.nchan = C; push(o); }
+        // inside an HRModule branch (jkey >= 0) the four CBAM launches take the next depth keys behind the block's two
+        // convolutions, so that group_jobs can put the module in depth-major order and merge the convolutions of its branches
+        auto key = [&]() { return jkey >= 0 ? jkey++ : -1; };
+        { Op o; o.kind = OP_POOL; o.in = x; o.out = partial; o.jkey = key(); push(o); }
+        { Op o; o.kind = OP_MLP; o.in = partial; o.out = cav; o.aux[0] = a0; o.aux[1] = a1; o.nchan = C; o.terms[0] = x; o.jkey = key(); push(o); }
+        { Op o; o.kind = OP_MAPS; o.in = x; o.terms[1] = cav; o.out = maps; o.nchan = C; o.jkey = key(); push(o); }
         { Op o; o.kind = OP_APPLY; o.in = x; o.res = res; o.terms[1] = cav; o.terms[2] = maps; o.aux[2] = a2;
-          o.out = y; o.c0 = y_c0; o.relu = relu; o.nchan = C; push(o); }
+          o.out = y; o.c0 = y_c0; o.relu = relu; o.nchan = C; o.jkey = key(); push(o); }
     }
     // BasicBlock of seg_hrnet3.py:64-103: conv-bn-relu-conv-bn, CBAM, (+res), relu
     int basic_block_cbam(const std::string& p, int x, int cin, int cout, int level, const std::string& tap) {
@@ -435,7 +438,7 @@ void group_jobs(esahrnet_ctx& c) {
         for (size_t a = i; a < j;) {
             size_t b = a;
             std::vector<size_t> mem;
-            const size_t cap = c.specs[c.dconvs[ops[a].dconv].spec].k == 1 ? 6 : 4;
+            const size_t cap = ops[a].kind == OP_CONV && c.specs[c.dconvs[ops[a].dconv].spec].k == 1 ? 6 : 4;
             while (b < j && ops[b].jkey == ops[a].jkey) { if (eligible(ops[b]) && mem.size() < cap) mem.push_back(b); ++b; }
             // members must be consecutive for the leader to stand for them: move the ineligible ones of this depth behind
             if (mem.size() >= 2) {
@@ -654,7 +657,8 @@ int build_plan_ops(esahrnet_ctx& c) {
             const std::string p = "stage" + std::to_string(s) + "." + std::to_string(m);
             for (int b = 0; b < nb; ++b) {
                 for (int k = 0; k < g.blocks[s - 1][b]; ++k) {
-                    B.jkey = (((s << 4) | m) << 8) | (2 * k);       // conv1 / conv2 of block k take 2k / 2k + 1
+                    // conv1 / conv2 of block k take keys 2k / 2k + 1 (seg_hrnet3: 6k .. 6k + 5 with the block's CBAM launches)
+                    B.jkey = (((s << 4) | m) << 8) | ((g.variant == 1 ? 6 : 2) * k);
                     xs[b] = B.basic_block(p + ".branches." + std::to_string(b) + "." + std::to_string(k),
                                           xs[b], cur[b], cur[b], 1 + b, "");
                     B.jkey = -1;
