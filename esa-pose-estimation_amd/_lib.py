@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libesahrnet.so")
 MAX_BRANCHES = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Cfg(C.Structure):
@@ -61,6 +61,11 @@ _SIGS = {
     "esahrnet_keypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "esahrnet_keypoints_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "esahrnet_partial_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "esahrnet_forward_partials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "esahrnet_keypoints_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
     "esahrnet_crops": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                  C.c_void_p, C.c_void_p]),
     "esahrnet_pnp_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

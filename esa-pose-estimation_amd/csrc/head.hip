@@ -144,6 +144,8 @@ int launch_final_t(const FinalParams& p, hipStream_t stream) {
 constexpr int MTH = 16, MTW = 16;                 // output tile
 constexpr int MIH = MTH + 2, MIW = MTW + 2;
 constexpr int MPLANE = ((MIH * MIW * 16 + 255) / 256) * 256;       // 5376 B, multiple of 256 B (bank-congruent planes)
+constexpr int MSRC = 12;                           // source window of a tile (rows and columns), see the staging
+__host__ __device__ constexpr bool final_wreg(int cg, int m) { return m == 1 && (9 * cg + 3) / 4 <= 7; }
 
 template <int CG, int M>
 __global__ __launch_bounds__(256, 2) void final_mfma_kernel(FinalParams p, const uint4* __restrict__ wpk, int tiles_x,
@@ -152,7 +154,11 @@ __global__ __launch_bounds__(256, 2) void final_mfma_kernel(FinalParams p, const
     constexpr int NCH = (NG + 3) / 4;             // 32-wide chunks
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const tile = smem;                      // [part][cg][pixel][16 B]
-    char* const wl = smem + 2 * CG * MPLANE;      // [m][chunk][part][lane][16 B]
+    // small weight sets stay in registers (10 fragments per lane for K <= 16, cin = 1): 10 KB of LDS less per workgroup,
+    // i.e. five instead of three workgroups per CU, and no LDS reads for the B operand
+    constexpr bool WREG = final_wreg(CG, M);
+    char* const wl = smem + 2 * CG * MPLANE;      // [m][chunk][part][lane][16 B]   (absent with WREG)
+    float* const srcf = reinterpret_cast<float*>(wl + (WREG ? 0 : M * NCH * 2048));      // [MSRC][MSRC][CG][8] f32 source window
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     int b = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -161,8 +167,35 @@ __global__ __launch_bounds__(256, 2) void final_mfma_kernel(FinalParams p, const
     const int n = b / tiles_y;
     const int oy0 = ty * MTH, ox0 = tx * MTW;
 
-    // ---- weights -> LDS ------------------------------------------------------------------------------
-    for (int u = tid; u < M * NCH * 2 * 64; u += 256) *reinterpret_cast<uint4*>(wl + u * 16) = wpk[u];
+    // ---- weights -> registers or LDS ------------------------------------------------------------------
+    uint4 wr[WREG ? 2 * NCH : 1];
+    if (WREG) {
+#pragma unroll
+        for (int c = 0; c < 2 * NCH; ++c) wr[c] = wpk[c * 64 + lane];          // [chunk][part][lane]
+    } else {
+        for (int u = tid; u < M * NCH * 2 * 64; u += 256) *reinterpret_cast<uint4*>(wl + u * 16) = wpk[u];
+    }
+
+    // ---- source window of the up-sampled keypoint channels -> LDS as f32, each source pixel unpacked ONCE ---------
+    // (x2 with align_corners=True: an 18-wide strip of the output covers at most 11 source columns; 12 with slack)
+    const int NKG = (p.K + 7) >> 3;               // channel groups that hold keypoint channels
+    const int gy_lo = max(oy0 - 1, 0), gy_hi = min(oy0 + MTH, p.H - 1);
+    const int gx_lo = max(ox0 - 1, 0), gx_hi = min(ox0 + MTW, p.W - 1);
+    const int sy0 = lerp_ac_true(gy_lo, p.h, p.H).i0, sx0 = lerp_ac_true(gx_lo, p.wd, p.W).i0;
+    const int srows = min(lerp_ac_true(gy_hi, p.h, p.H).i1 - sy0 + 1, MSRC);
+    const int scols = min(lerp_ac_true(gx_hi, p.wd, p.W).i1 - sx0 + 1, MSRC);
+    for (int u = tid; u < srows * scols * NKG; u += 256) {
+        const int kg = u % NKG;
+        const int q = u / NKG;
+        const int sy = q / scols, sx = q - sy * scols;
+        const char* a = p.h3 + (((size_t)n * p.h + sy0 + sy) * p.wd + sx0 + sx) * ((size_t)p.Cp * 4) + kg * 32;
+        float v[8];
+        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+        float* o = srcf + ((sy * MSRC + sx) * CG + kg) * 8;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    __syncthreads();
 
     // ---- concat tile -> LDS operand planes: unit = (pixel, channel group) --------------------------
     for (int u = tid; u < MIH * MIW * CG; u += 256) {
@@ -176,22 +209,24 @@ __global__ __launch_bounds__(256, 2) void final_mfma_kernel(FinalParams p, const
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
             if (cg * 8 < p.K) {                   // up-sampled keypoint channels of this group
                 const LerpT ly = lerp_ac_true(gy, p.h, p.H), lx = lerp_ac_true(gx, p.wd, p.W);
-                const size_t r0 = ((size_t)n * p.h + ly.i0) * p.wd, r1 = ((size_t)n * p.h + ly.i1) * p.wd;
-                const size_t ps = (size_t)p.Cp * 4;
-                float v00[8], v01[8], v10[8], v11[8];
-                const char* a;
-                a = p.h3 + (r0 + lx.i0) * ps + cg * 32;
-                join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v00);
-                a = p.h3 + (r0 + lx.i1) * ps + cg * 32;
-                join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v01);
-                a = p.h3 + (r1 + lx.i0) * ps + cg * 32;
-                join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v10);
-                a = p.h3 + (r1 + lx.i1) * ps + cg * 32;
-                join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v11);
+                const int r0 = min(ly.i0 - sy0, MSRC - 1) * MSRC, r1 = min(ly.i1 - sy0, MSRC - 1) * MSRC;
+                const int c0 = min(lx.i0 - sx0, MSRC - 1), c1 = min(lx.i1 - sx0, MSRC - 1);
+                const float* a00 = srcf + ((r0 + c0) * CG + cg) * 8;
+                const float* a01 = srcf + ((r0 + c1) * CG + cg) * 8;
+                const float* a10 = srcf + ((r1 + c0) * CG + cg) * 8;
+                const float* a11 = srcf + ((r1 + c1) * CG + cg) * 8;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float4 v00 = *reinterpret_cast<const float4*>(a00 + 4 * hf), v01 = *reinterpret_cast<const float4*>(a01 + 4 * hf);
+                    const float4 v10 = *reinterpret_cast<const float4*>(a10 + 4 * hf), v11 = *reinterpret_cast<const float4*>(a11 + 4 * hf);
+                    v[4 * hf + 0] = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+                    v[4 * hf + 1] = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+                    v[4 * hf + 2] = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+                    v[4 * hf + 3] = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    if (cg * 8 + i < p.K)
-                        v[i] = ly.l0 * (lx.l0 * v00[i] + lx.l1 * v01[i]) + ly.l1 * (lx.l0 * v10[i] + lx.l1 * v11[i]);
+                    if (cg * 8 + i >= p.K) v[i] = 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {         // raw input channels that fall into this group
@@ -229,8 +264,13 @@ __global__ __launch_bounds__(256, 2) void final_mfma_kernel(FinalParams p, const
         bf16x8 wh[M], wlo[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            wh[m] = *reinterpret_cast<const bf16x8*>(wl + (((m * NCH + c) * 2 + 0) * 64 + lane) * 16);
-            wlo[m] = *reinterpret_cast<const bf16x8*>(wl + (((m * NCH + c) * 2 + 1) * 64 + lane) * 16);
+            if (WREG) {
+                wh[m] = __builtin_bit_cast(bf16x8, wr[WREG ? 2 * c : 0]);
+                wlo[m] = __builtin_bit_cast(bf16x8, wr[WREG ? 2 * c + 1 : 0]);
+            } else {
+                wh[m] = *reinterpret_cast<const bf16x8*>(wl + (((m * NCH + c) * 2 + 0) * 64 + lane) * 16);
+                wlo[m] = *reinterpret_cast<const bf16x8*>(wl + (((m * NCH + c) * 2 + 1) * 64 + lane) * 16);
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -260,6 +300,41 @@ __global__ __launch_bounds__(256, 2) void final_mfma_kernel(FinalParams p, const
             }
         }
     }
+    // ---- optional: the tile's first row-major maximum of every heat-map (keypoints.hip finishes over the tiles) ----
+    if (p.part) {
+        float* const pv = srcf + MSRC * MSRC * CG * 8;          // [wave][M*16] value, then [wave][M*16] index
+        int* const pi = reinterpret_cast<int*>(pv + 4 * M * 16);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int oy = oy0 + wave * 4 + t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ox = ox0 + g * 4 + r;
+                    if (oy < p.H && ox < p.W) argmax_take(acc[m][t][r], oy * p.W + ox, bv, bi);
+                }
+            }
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                argmax_take(ov, oi, bv, bi);
+            }
+            if (g == 0) { pv[wave * (M * 16) + m * 16 + i16] = bv; pi[wave * (M * 16) + m * 16 + i16] = bi; }
+        }
+        __syncthreads();
+        if (tid < M * 16 && tid < p.K) {
+            float bv = pv[tid];
+            int bi = pi[tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) argmax_take(pv[w * (M * 16) + tid], pi[w * (M * 16) + tid], bv, bi);
+            const int tile_id = ty * tiles_x + tx;
+            p.part[((size_t)n * p.K + tid) * (size_t)(tiles_x * tiles_y) + tile_id] = make_float2(bv, __int_as_float(bi));
+        }
+    }
 }
 
 template <int CG, int M>
@@ -268,7 +343,7 @@ int launch_final_mfma_t(const FinalParams& p, hipStream_t stream) {
     const int tiles_x = (p.W + MTW - 1) / MTW, tiles_y = (p.H + MTH - 1) / MTH;
     const long long nblk = (long long)p.N * tiles_x * tiles_y;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    const int lds = 2 * CG * MPLANE + M * NCH * 2048;
+    const int lds = 2 * CG * MPLANE + (final_wreg(CG, M) ? 0 : M * NCH * 2048) + MSRC * MSRC * CG * 32 + 4 * M * 16 * 8;
     auto kern = final_mfma_kernel<CG, M>;
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, p, p.wpk, tiles_x, tiles_y);
@@ -297,6 +372,10 @@ int final_kt(int K) { return K <= 11 ? 11 : (K <= 16 ? 16 : (K <= 32 ? 32 : -1))
 bool final_mfma_supported(int K, int cin) {
     const int cg = (K + cin + 7) / 8;
     return K >= 1 && K <= 32 && cg >= 2 && cg <= 5;
+}
+int final_part_tiles(int K, int cin, int H, int W) {
+    if (!final_mfma_supported(K, cin) || H <= 0 || W <= 0) return 0;
+    return ((W + MTW - 1) / MTW) * ((H + MTH - 1) / MTH);
 }
 size_t final_mfma_bytes(int K, int cin) {
     const int cg = (K + cin + 7) / 8, m = (K + 15) / 16, nch = (9 * cg + 3) / 4;

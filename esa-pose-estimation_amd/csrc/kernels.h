@@ -122,8 +122,17 @@ struct FinalParams {
     int N, H, W, h, wd; // h,wd = resolution of h3
     int K, cin, Cp;
     int bf;             // 1: h3 is a BF tensor (VALU kernel only)
+    float2* part;       // optional (MFMA kernel only): [N*K][final_part_tiles] (value, index bits) of every tile's first maximum
 };
 int launch_final(const FinalParams& p, hipStream_t stream);
+// tiles per heat-map the MFMA output-layer kernel reports partial maxima for; 0: that kernel does not serve (K, cin)
+int final_part_tiles(int K, int cin, int H, int W);
+// (v, i) beats (bv, bi) if it is larger — NaN counting as larger than every number — or equal with a lower index
+// (np.argmax / torch.max: first row-major maximum, first NaN)
+__device__ __forceinline__ void argmax_take(float v, int i, float& bv, int& bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (v > bv || (vn && !bn) || ((v == bv || (vn && bn)) && i < bi)) { bv = v; bi = i; }
+}
 bool final_mfma_supported(int K, int cin);
 size_t final_mfma_bytes(int K, int cin);
 void pack_final_mfma(const float* w, int K, int cin, void* dst);
@@ -220,6 +229,9 @@ int launch_head_gather(GatherParams p, hipStream_t stream);
 // ---- arg-max + log-quadratic refine (keypoints.hip) ----------------------------------------
 // idx_out: optional int32 [planes], the flat index (row * W + column) of the arg-max
 int launch_keypoints(const float* heat, int planes, int H, int W, float* kp, int* idx_out, hipStream_t stream);
+// same result from the per-tile maxima of the output-layer kernel (FinalParams::part, `ntiles` pairs per plane)
+int launch_keypoints_finish(const float* heat, const float2* part, int ntiles, int planes, int H, int W, float* kp, int* idx_out,
+                            hipStream_t stream);
 
 // ---- crop + edge-pad + 8-bit bilinear resize + normalise: u8 frames -> f32 [N][1][S][S] (crops.hip) ----
 int launch_crops(const unsigned char* frames, const int* boxes, float* out, int N, int FH, int FW, int S,

@@ -1355,7 +1355,7 @@ int esahrnet_workspace_bytes(esahrnet_handle h, int n, int height, int width, si
 
 static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, int width,
                        void* heat_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream_,
-                       hipEvent_t* events) {
+                       hipEvent_t* events, void* part_dev = nullptr) {
     if (!h || !x_dev || !heat_dev || !ws_dev) return fail("forward: null argument");
     if (!h->committed) return fail("forward: esahrnet_commit has not been called");
     if (plan_shape(*h, n, height, width)) return 1;
@@ -1634,6 +1634,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 p.w = h->final_w; p.bias = h->final_b; p.wpk = static_cast<const uint4*>(h->final_wpk);
                 p.N = n; p.H = height; p.W = width; p.h = sp.lh[ti.level]; p.wd = sp.lw[ti.level];
                 p.K = h->cfg.num_keypoints; p.cin = h->cfg.cin; p.Cp = ti.Cp; p.bf = h->bf ? 1 : 0;
+                p.part = static_cast<float2*>(part_dev);
                 rc = esa::launch_final(p, stream);
                 break;
             }
@@ -1866,6 +1867,36 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             break;
         }
     }
+    return 0;
+}
+
+int esahrnet_partial_tiles(esahrnet_handle h, int height, int width, int* ntiles) {
+    if (!h || !ntiles) return fail("partial_tiles: null argument");
+    if (!h->committed) return fail("partial_tiles: esahrnet_commit has not been called");
+    *ntiles = 0;
+    // only the matrix-core output-layer kernel of the split-bf16 seg_hrnet / seg_hrnet2 plans reports per-tile maxima
+    if (h->cfg.variant == 0 && !h->bf && h->final_wpk)
+        *ntiles = esa::final_part_tiles(h->cfg.num_keypoints, h->cfg.cin, height, width);
+    return 0;
+}
+
+int esahrnet_forward_partials(esahrnet_handle h, const void* x_dev, int n, int height, int width, void* heat_dev,
+                              void* part_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream) {
+    int nt = 0;
+    if (part_dev) {
+        if (esahrnet_partial_tiles(h, height, width, &nt)) return 1;
+        if (nt <= 0) return fail("forward_partials: this handle's output layer does not report per-tile maxima (esahrnet_partial_tiles = 0)");
+    }
+    return run_forward(h, x_dev, n, height, width, heat_dev, ws_dev, ws_bytes, stream, nullptr, part_dev);
+}
+
+int esahrnet_keypoints_finish(const void* heat_dev, const void* part_dev, int ntiles, int n, int k, int height, int width,
+                              void* kp_dev, void* idx_dev, esahrnet_stream stream) {
+    if (!heat_dev || !part_dev || !kp_dev || n <= 0 || k <= 0 || ntiles <= 0) return fail("keypoints_finish: bad argument");
+    const int rc = esa::launch_keypoints_finish(static_cast<const float*>(heat_dev), static_cast<const float2*>(part_dev), ntiles,
+                                                n * k, height, width, static_cast<float*>(kp_dev), static_cast<int*>(idx_dev),
+                                                static_cast<hipStream_t>(stream));
+    if (rc) return fail("keypoints_finish: %s", hipGetErrorString((hipError_t)rc));
     return 0;
 }
 

@@ -229,6 +229,7 @@ class _Runtime:
         self.handles = {}        # device index -> (handle, weight-version key)
         self.dev_locks = {}      # device index -> lock serialising the enqueues of that device's handle
         self.ws = {}             # (device, stream, n, h, w, keep) -> uint8 tensor, insertion order = LRU order
+        self.part_tiles = {}     # (handle, h, w) -> tiles per heat-map with partial maxima (0: none)
         self._probe = self._create(-1)
 
     def _create(self, device):
@@ -354,16 +355,34 @@ class _Runtime:
             _lib.check(self.lib.esahrnet_set_debug_keep(h, 1 if keep else 0))
             ws, ws_ptr, ws_bytes = self._workspace(h, dev, ts, n, hh, ww, keep)
             heat = torch.empty((n, module._k, hh, ww), dtype=torch.float32, device=dev)
-            args = (h, x.data_ptr(), n, hh, ww, heat.data_ptr(), ws_ptr, ws_bytes, C.c_void_p(ts.cuda_stream))
+            # per-tile maxima beside the heat-maps (include/esahrnet.h: esahrnet_forward_partials): 8 bytes per plane
+            # and 16x16 tile, so that inference.heatmaps_to_keypoints need not sweep the maps again
+            nt = self._partial_tiles(h, hh, ww)
+            part = torch.empty((n * module._k, nt, 2), dtype=torch.float32, device=dev) if nt else None
+            args = (h, x.data_ptr(), n, hh, ww, heat.data_ptr(), part.data_ptr() if nt else None, ws_ptr, ws_bytes,
+                    C.c_void_p(ts.cuda_stream))
             if torch.cuda.current_device() == dev.index:
-                rc = self.lib.esahrnet_forward(*args)
+                rc = self.lib.esahrnet_forward_partials(*args)
             else:
                 with torch.cuda.device(dev):
-                    rc = self.lib.esahrnet_forward(*args)
+                    rc = self.lib.esahrnet_forward_partials(*args)
             _lib.check(rc)
         ws.record_stream(ts)
         x.record_stream(ts)
+        if nt:
+            heat._esa_partials = (part, nt, heat._version)
         return heat
+
+    def _partial_tiles(self, h, hh, ww):
+        if os.environ.get("ESAHRNET_NO_PARTIALS"):
+            return 0
+        key = (getattr(h, "value", h), hh, ww)
+        nt = self.part_tiles.get(key)
+        if nt is None:
+            v = C.c_int(0)
+            _lib.check(self.lib.esahrnet_partial_tiles(h, hh, ww, C.byref(v)))
+            nt = self.part_tiles[key] = v.value
+        return nt
 
     def forward_timed(self, module, x0):
         x = self._check_input(module, x0)

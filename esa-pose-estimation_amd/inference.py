@@ -28,14 +28,25 @@ def _keypoints(heat: torch.Tensor, want_index: bool):
         raise RuntimeError("heatmaps_to_keypoints runs on the GPU only (no CPU fallback)")
     if heat.dtype != torch.float32:
         raise TypeError(f"expected float32 heatmaps, got {heat.dtype}")
+    # heat-maps that come straight out of a forward carry the per-tile maxima their output-layer kernel found
+    # (hrnet._Runtime.forward): finishing over those gives the same bits without reading the maps again.  The note is
+    # honoured only for this very tensor object, unmodified since (views, clones and in-place edits take the full sweep).
+    note = getattr(heat, "_esa_partials", None)
+    if note is not None and (note[2] != heat._version or not heat.is_contiguous() or note[0].device != heat.device):
+        note = None
     heat = heat.contiguous()
     n, k, h, w = heat.shape
     kp = torch.empty((n, k, 3), dtype=torch.float32, device=heat.device)
     idx = torch.empty((n, k), dtype=torch.int32, device=heat.device) if want_index else None
     stream = torch.cuda.current_stream(heat.device).cuda_stream
     with torch.cuda.device(heat.device):
-        _lib.check(_lib.lib().esahrnet_keypoints_ex(heat.data_ptr(), n, k, h, w, kp.data_ptr(),
-                                                    idx.data_ptr() if want_index else None, C.c_void_p(stream)))
+        if note is not None:
+            _lib.check(_lib.lib().esahrnet_keypoints_finish(heat.data_ptr(), note[0].data_ptr(), note[1], n, k, h, w,
+                                                            kp.data_ptr(), idx.data_ptr() if want_index else None,
+                                                            C.c_void_p(stream)))
+        else:
+            _lib.check(_lib.lib().esahrnet_keypoints_ex(heat.data_ptr(), n, k, h, w, kp.data_ptr(),
+                                                        idx.data_ptr() if want_index else None, C.c_void_p(stream)))
     return kp, idx
 
 

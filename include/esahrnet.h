@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define ESAHRNET_MAX_BRANCHES 4
-#define ESAHRNET_ABI_VERSION 3
+#define ESAHRNET_ABI_VERSION 4
 
 typedef struct esahrnet_ctx* esahrnet_handle;
 typedef void* esahrnet_stream; /* hipStream_t */
@@ -114,6 +114,20 @@ int esahrnet_keypoints(const void* heat_dev, int n, int k, int height, int width
  * np.argmax / torch.max: first NaN's index, peak NaN, no refinement. */
 int esahrnet_keypoints_ex(const void* heat_dev, int n, int k, int height, int width,
                           void* kp_dev, void* idx_dev, esahrnet_stream stream);
+
+/* ---- forward + keypoints without re-reading the heat-maps -------------------------------------------------
+ * The output-layer kernel can leave, beside the heat-maps, the first row-major maximum of each of its tiles:
+ * part_dev = 8 bytes x [n * K][ntiles] (f32 value, int32 index row * width + column).  esahrnet_keypoints_finish reduces
+ * those instead of sweeping n*K*height*width floats; its results are bit-identical to esahrnet_keypoints_ex on the same
+ * heat-maps (same ordering of ties and NaNs, same refinement).  Replaces: `net(x)` followed by get_final / the host peak
+ * search (val.py:151-166, inference.py:136-152).
+ * esahrnet_partial_tiles: ntiles for a crop size; 0 = this handle cannot (bf16 precision, seg_hrnet3, VALU output layer):
+ * use esahrnet_forward + esahrnet_keypoints.  part_dev == NULL makes esahrnet_forward_partials plain esahrnet_forward. */
+int esahrnet_partial_tiles(esahrnet_handle h, int height, int width, int* ntiles);
+int esahrnet_forward_partials(esahrnet_handle h, const void* x_dev, int n, int height, int width, void* heat_dev,
+                              void* part_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream);
+int esahrnet_keypoints_finish(const void* heat_dev, const void* part_dev, int ntiles, int n, int k, int height, int width,
+                              void* kp_dev, void* idx_dev, esahrnet_stream stream);
 
 /* Loader stage in front of the path (data_load_val.py:139-187): for each of n 8-bit frames
  * [frame_h][frame_w] take the clamped box boxes[i] = (x0, y0, x1, y1) (int32, device), edge-pad it the

@@ -509,6 +509,45 @@ def test_hrnet3_head_by_linearity_matches_oracle_and_direct_form(env, monkeypatc
     assert (y_d - y).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 1, 64, 64), (2, 1, 48, 80), (2, 1, 34, 18), (5, 3, 96, 64)])
+def test_keypoints_from_tile_maxima_equal_the_full_sweep(env, shape):
+    """The output-layer kernel leaves each 16x16 tile's first maximum beside the heat-maps and
+    heatmaps_to_keypoints(net(x)) finishes over those (esahrnet_forward_partials / esahrnet_keypoints_finish) instead of
+    sweeping the maps again.  Must be bit-identical to the full sweep on the same maps (a clone carries no note), for tile
+    remainders (34x18), both variants, with ties (a constant plane: first index), and must not be used for a tensor
+    that was modified after the forward."""
+    variant = "seg_hrnet" if shape[1] == 3 else "seg_hrnet2"
+    net, sd = _build(env, variant, (8, 16, 32, 64), 51)
+    x = env["synth"].make_crops(*shape, seed=51).cuda()
+    inf = env["inference"]
+    with torch.no_grad():
+        heat = net(x)
+        assert getattr(heat, "_esa_partials", None) is not None
+        kp_fast = inf.heatmaps_to_keypoints(heat)
+        kp_full = inf.heatmaps_to_keypoints(heat.clone())
+        preds_fast, vals_fast = inf.get_max_preds(heat)
+        preds_full, vals_full = inf.get_max_preds(heat.clone())
+    assert torch.equal(kp_fast, kp_full)
+    assert np.array_equal(np.asarray(preds_fast), np.asarray(preds_full)) and np.array_equal(np.asarray(vals_fast), np.asarray(vals_full))
+    ref = env["kref"].heatmaps_to_keypoints(heat.cpu().numpy())
+    assert np.allclose(kp_fast.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    # in-place edit after the forward: the note is stale and must be ignored
+    with torch.no_grad():
+        heat[0, 0, 5, 7] = 1e9
+        kp_edit = inf.heatmaps_to_keypoints(heat)
+    assert kp_edit[0, 0, 2].item() == 1e9 and abs(kp_edit[0, 0, 0].item() - 7) < 1 and abs(kp_edit[0, 0, 1].item() - 5) < 1
+    # ties: zero weights in the output layer -> every plane is the constant bias -> first index (0, 0)
+    sd0 = {k: v.clone() for k, v in sd.items()}
+    sd0["output_layer.0.weight"].zero_()
+    net.load_state_dict(sd0)
+    with torch.no_grad():
+        heat0 = net(x)
+        kp0 = inf.heatmaps_to_keypoints(heat0)
+        kp0_full = inf.heatmaps_to_keypoints(heat0.clone())
+    assert torch.equal(kp0, kp0_full)
+    assert (kp0[..., :2] == 0).all()
+
+
 # ------------------------------------------------------------------------------------- boundary (round 2)
 def test_dataparallel_wrapper_and_replicas(env):
     """val.py:380-388: `net = DataParallel(NetWrapper(net)).cuda()`, weights loaded through `net.module.net`,
