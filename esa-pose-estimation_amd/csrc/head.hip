@@ -188,9 +188,14 @@ __global__ __launch_bounds__(256, 2) void final_mfma_kernel(FinalParams p, const
         const int kg = u % NKG;
         const int q = u / NKG;
         const int sy = q / scols, sx = q - sy * scols;
-        const char* a = p.h3 + (((size_t)n * p.h + sy0 + sy) * p.wd + sx0 + sx) * ((size_t)p.Cp * 4) + kg * 32;
         float v[8];
-        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+        if (p.bf) {         // single-bf16 tensor (precision = 1): 2 bytes per channel
+            const char* a = p.h3 + (((size_t)n * p.h + sy0 + sy) * p.wd + sx0 + sx) * ((size_t)p.Cp * 2) + kg * 16;
+            unpack8_bf16(*reinterpret_cast<const uint4*>(a), v);
+        } else {
+            const char* a = p.h3 + (((size_t)n * p.h + sy0 + sy) * p.wd + sx0 + sx) * ((size_t)p.Cp * 4) + kg * 32;
+            join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+        }
         float* o = srcf + ((sy * MSRC + sx) * CG + kg) * 8;
         *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);

@@ -1270,7 +1270,7 @@ int esahrnet_commit(esahrnet_handle h) {
         const ConvSpec& s = h->specs[h->spec_final];
         const int kt = esa::final_kt(s.cout);
         std::vector<float> w((size_t)s.cin * 9 * kt, 0.f), b(std::max(kt, 32), 0.f);
-        if (!h->bf && esa::final_mfma_supported(s.cout, s.cin - s.cout) && !getenv("ESAHRNET_FINAL_VALU")) {
+        if (esa::final_mfma_supported(s.cout, s.cin - s.cout) && !getenv("ESAHRNET_FINAL_VALU")) {
             packed.assign(esa::final_mfma_bytes(s.cout, s.cin - s.cout), 0);
             esa::pack_final_mfma(s.w.data(), s.cout, s.cin - s.cout, packed.data());
             if (upload(packed, &h->final_wpk)) return 1;
@@ -1874,8 +1874,8 @@ int esahrnet_partial_tiles(esahrnet_handle h, int height, int width, int* ntiles
     if (!h || !ntiles) return fail("partial_tiles: null argument");
     if (!h->committed) return fail("partial_tiles: esahrnet_commit has not been called");
     *ntiles = 0;
-    // only the matrix-core output-layer kernel of the split-bf16 seg_hrnet / seg_hrnet2 plans reports per-tile maxima
-    if (h->cfg.variant == 0 && !h->bf && h->final_wpk)
+    // only the matrix-core output-layer kernel of the seg_hrnet / seg_hrnet2 plans reports per-tile maxima
+    if (h->cfg.variant == 0 && h->final_wpk)
         *ntiles = esa::final_part_tiles(h->cfg.num_keypoints, h->cfg.cin, height, width);
     return 0;
 }

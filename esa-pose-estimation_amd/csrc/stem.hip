@@ -67,10 +67,83 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, long long total
     *reinterpret_cast<uint4*>(o + 16) = lo;
 }
 
+// cin == 1 (seg_hrnet2 / seg_hrnet3): the 72 weights of a thread's 8-channel group live in registers and the thread walks
+// STEM_PX consecutive pixels of a row — the kernel above re-reads them from LDS for every pixel (288 bytes of LDS per
+// 72 multiply-adds: LDS-bound at 1.7 TB/s of output), and each input sample now serves up to three pixels from a register.
+constexpr int STEM_PX = 8;
+__global__ __launch_bounds__(256) void stem1_kernel(StemParams p, int xgroups, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int G = p.cout >> 3;
+    const int c8 = (int)(idx % G);
+    long long q = idx / G;
+    const int xg = (int)(q % xgroups);
+    q /= xgroups;
+    const int y = (int)(q % p.H);
+    const int n = (int)(q / p.H);
+    const int x0 = xg * STEM_PX;
+    float w[72], b[8];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + (size_t)c8 * 72 + i * 4);
+        w[4 * i] = v[0]; w[4 * i + 1] = v[1]; w[4 * i + 2] = v[2]; w[4 * i + 3] = v[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = p.bias[c8 * 8 + i];
+    const float* xp = p.x + (size_t)n * p.H * p.W;
+    float in[3][STEM_PX + 2];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+#pragma unroll
+        for (int k = 0; k < STEM_PX + 2; ++k) {
+            const int xx = x0 + k - 1;
+            in[ky][k] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? xp[(size_t)yy * p.W + xx] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int px = 0; px < STEM_PX; ++px) {
+        const int x = x0 + px;
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = b[i];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float v = in[ky][px + kx];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(v, w[(ky * 3 + kx) * 8 + i], acc[i]);     // same order as stem_kernel
+            }
+        if (p.relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = relu1(acc[i]);
+        }
+        if (x >= p.W) continue;
+        if (p.bf) {
+            *reinterpret_cast<uint4*>(p.y + (((size_t)(n * p.H + y) * p.W + x) * p.cout) * 2 + c8 * 16) = pack8_bf16(acc);
+        } else {
+            uint4 hi, lo;
+            split8(acc, hi, lo);
+            char* o = p.y + (((size_t)(n * p.H + y) * p.W + x) * p.cout) * 4 + c8 * 32;
+            *reinterpret_cast<uint4*>(o) = hi;
+            *reinterpret_cast<uint4*>(o + 16) = lo;
+        }
+    }
+}
+
 }  // namespace
 
 int launch_stem(const StemParams& p, hipStream_t stream) {
     if ((p.cout & 31) || p.cin < 1 || p.cin > 4) return (int)hipErrorInvalidValue;
+    if (p.cin == 1) {
+        const int xgroups = (p.W + STEM_PX - 1) / STEM_PX;
+        const long long total1 = (long long)p.N * p.H * xgroups * (p.cout >> 3);
+        const long long nblk1 = (total1 + 255) / 256;
+        if (nblk1 <= 0 || nblk1 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(stem1_kernel, dim3((unsigned)nblk1), dim3(256), 0, stream, p, xgroups, total1);
+        return (int)hipGetLastError();
+    }
     const long long total = (long long)p.N * p.H * p.W * (p.cout >> 3);
     const long long nblk = (total + 255) / 256;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
