@@ -188,6 +188,99 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(CbamApplyParams p, long
     *reinterpret_cast<uint4*>(o + 16) = lo;
 }
 
+// ---- cbam_spatial: cbam_maps + cbam_apply in one pass over a 16 x 32 tile (+ 3-pixel halo for the 7x7) -------------
+// The two kernels above read x twice and hand the 2-channel maps through HBM.  Here a workgroup forms the maps of its
+// halo'd tile in LDS (the halo pixels' x comes out of L2: the neighbouring tiles read them too), evaluates the 7x7 spatial
+// attention from there and applies it.  thread = (pixel, 8-channel group), the G = Cp/8 threads of a pixel are
+// neighbouring lanes (G a power of two <= 32): channel reductions and the 49 taps are shared by xor-shuffles.
+constexpr int CS_TH = 16, CS_TW = 32, CS_HH = CS_TH + 6, CS_HW = CS_TW + 6;
+__global__ __launch_bounds__(256) void cbam_spatial_kernel(CbamApplyParams p, int tiles_x, int tiles_y) {
+    __shared__ float mp[CS_HH * CS_HW * 2];
+    __shared__ float w[98];
+    const int tid = threadIdx.x;
+    int b = (int)blockIdx.x;
+    const int tx0 = (b % tiles_x) * CS_TW; b /= tiles_x;
+    const int ty0 = (b % tiles_y) * CS_TH;
+    const int n = b / tiles_y;
+    if (tid < 98) w[tid] = p.w_sa[tid];
+    const int G = p.Cp >> 3, PPB = 256 / G;
+    const int lg = tid & (G - 1), pl = tid / G;
+    float cn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cn[i] = p.ca[(size_t)n * p.Cp + lg * 8 + i];
+    const size_t img = (size_t)n * p.H * p.W;
+    // ---- maps of the halo'd tile (zero outside the image: the 7x7 convolution's padding); four pixels per thread in
+    // flight: a single dependent load per loop trip left the kernel latency-bound ----
+    for (int q0 = pl; q0 < CS_HH * CS_HW; q0 += 4 * PPB) {
+        uint4 h4[4], l4[4];
+        bool inside[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = q0 + k * PPB;
+            const int hy = q / CS_HW, hx = q - hy * CS_HW;
+            const int Y = ty0 - 3 + hy, X = tx0 - 3 + hx;
+            inside[k] = q < CS_HH * CS_HW && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+            h4[k] = make_uint4(0, 0, 0, 0); l4[k] = make_uint4(0, 0, 0, 0);
+            if (inside[k] && lg * 8 < p.C) {
+                const char* a = p.x + (img + (size_t)Y * p.W + X) * (size_t)(p.Cp * 4) + lg * 32;
+                h4[k] = *reinterpret_cast<const uint4*>(a);
+                l4[k] = *reinterpret_cast<const uint4*>(a + 16);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = q0 + k * PPB;
+            float s = 0.f, m = -INFINITY;
+            if (inside[k] && lg * 8 < p.C) {
+                float v[8];
+                join8(h4[k], l4[k], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (lg * 8 + i < p.C) { const float u = v[i] * cn[i]; s += u; m = fmaxf(m, u); }
+            }
+            for (int off = G >> 1; off >= 1; off >>= 1) { s += __shfl_xor(s, off); m = fmaxf(m, __shfl_xor(m, off)); }
+            if (lg == 0 && q < CS_HH * CS_HW) { mp[q * 2] = inside[k] ? s / (float)p.C : 0.f; mp[q * 2 + 1] = inside[k] ? m : 0.f; }
+        }
+    }
+    __syncthreads();
+    // ---- spatial attention + apply ----
+    for (int q = pl; q < CS_TH * CS_TW; q += PPB) {
+        const int py = q / CS_TW, px = q - py * CS_TW;
+        const int Y = ty0 + py, X = tx0 + px;
+        float part = 0.f;
+        for (int t = lg; t < 49; t += G) {
+            const int ky = t / 7, kx = t - ky * 7;
+            const float* mq = mp + ((py + ky) * CS_HW + px + kx) * 2;
+            part += w[t] * mq[0] + w[49 + t] * mq[1];
+        }
+        for (int off = G >> 1; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+        if (Y >= p.H || X >= p.W) continue;
+        const float sa = sigmoidf(part);
+        const size_t idx = img + (size_t)Y * p.W + X;
+        const char* a = p.x + idx * (size_t)(p.Cp * 4) + lg * 32;
+        float v[8];
+        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (sa * cn[i]) * v[i];
+        if (p.res) {
+            const char* r = p.res + idx * (size_t)(p.Cp * 4) + lg * 32;
+            float rv[8];
+            join8(*reinterpret_cast<const uint4*>(r), *reinterpret_cast<const uint4*>(r + 16), rv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += rv[i];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        char* o = p.y + idx * (size_t)p.y_pix_bytes + ((p.y_c0 >> 3) + lg) * 32;
+        *reinterpret_cast<uint4*>(o) = hi;
+        *reinterpret_cast<uint4*>(o + 16) = lo;
+    }
+}
+
 // ---- resample_slice: thread = (dst pixel, 8-channel group of the source) ---------------------------------
 struct LerpR { int i0, i1; float l0, l1; };
 __device__ __forceinline__ LerpR lerp_any(int dst, int in, int out, int align) {
@@ -281,6 +374,20 @@ int launch_cbam_apply(const CbamApplyParams& p, hipStream_t s) {
     if ((p.y_c0 & 7) || (p.Cp & 7) || p.Cp > 2048 || p.Cp < 8) return (int)hipErrorInvalidValue;
     const int ppb = 256 / (p.Cp >> 3);
     hipLaunchKernelGGL(cbam_apply_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, s, p, npix);
+    return (int)hipGetLastError();
+}
+
+bool cbam_spatial_supported(int Cp) {
+    const int G = Cp >> 3;
+    return (Cp & 7) == 0 && G >= 1 && G <= 32 && (G & (G - 1)) == 0;
+}
+
+int launch_cbam_spatial(const CbamApplyParams& p, hipStream_t s) {
+    if (!cbam_spatial_supported(p.Cp) || (p.y_c0 & 7) || p.C < 1 || p.C > p.Cp) return (int)hipErrorInvalidValue;
+    const int tiles_x = (p.W + CS_TW - 1) / CS_TW, tiles_y = (p.H + CS_TH - 1) / CS_TH;
+    const long long nblk = (long long)tiles_x * tiles_y * p.N;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cbam_spatial_kernel, dim3((unsigned)nblk), dim3(256), 0, s, p, tiles_x, tiles_y);
     return (int)hipGetLastError();
 }
 

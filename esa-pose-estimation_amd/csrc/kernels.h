@@ -204,8 +204,12 @@ struct CbamApplyParams {
     const float* w_sa;  // f32 [2][7][7]
     char* y;            // SB, pixel pitch y_pix_bytes, written at channel offset y_c0 (multiple of 8)
     int N, H, W, Cp, y_pix_bytes, y_c0, relu;
+    int C;              // real channels (cbam_spatial only: it forms the maps itself and ignores `maps`)
 };
 int launch_cbam_apply(const CbamApplyParams& p, hipStream_t s);
+// maps + apply in one pass (no `maps` tensor); Cp / 8 must be a power of two <= 32
+bool cbam_spatial_supported(int Cp);
+int launch_cbam_spatial(const CbamApplyParams& p, hipStream_t s);
 struct ResampleParams {
     const char* x;      // SB [N][h][w][Cp_src]
     char* y;            // SB [N][H][W][..], pixel pitch y_pix_bytes, channel offset y_c0 (multiple of 8)

@@ -1353,6 +1353,15 @@ int esahrnet_workspace_bytes(esahrnet_handle h, int n, int height, int width, si
     return 0;
 }
 
+// CBAM's per-pixel maps and their 7x7 attention in one kernel (cbam.hip: cbam_spatial) where the channel-group count allows
+// and the image has at least 32 of its 16 x 32 tiles (measured, batch 32: 128x128x32ch 69 -> 47 us, 256x256x64ch 448 -> 323 us,
+// but 64x64 and smaller lose: too few workgroups, each walking a halo that is mostly padding).  The batch size is
+// deliberately not part of the rule: the kernel serving a layer must not depend on it.
+static bool cbam_fused(int Cp, int hh, int ww) {
+    static const bool off = getenv("ESAHRNET_CBAM_UNFUSED") != nullptr;
+    return !off && esa::cbam_spatial_supported(Cp) && ((hh + 15) / 16) * ((ww + 31) / 32) >= 32;
+}
+
 static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, int width,
                        void* heat_dev, void* ws_dev, size_t ws_bytes, esahrnet_stream stream_,
                        hipEvent_t* events, void* part_dev = nullptr) {
@@ -1435,6 +1444,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
             }
             case OP_MAPS: {
                 const Tensor& ti = h->tensors[o.in];
+                if (cbam_fused(ti.Cp, sp.lh[ti.level], sp.lw[ti.level])) break;      // formed inside cbam_spatial (the OP_APPLY that follows)
                 rc = esa::launch_cbam_maps(T(o.in), reinterpret_cast<const float*>(T(o.terms[1])),
                                            reinterpret_cast<float*>(T(o.out)), n, sp.lh[ti.level] * sp.lw[ti.level],
                                            o.nchan, ti.Cp, stream);
@@ -1448,8 +1458,8 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 p.ca = reinterpret_cast<const float*>(T(o.terms[1])); p.maps = reinterpret_cast<const float*>(T(o.terms[2]));
                 p.w_sa = h->aux[o.aux[2]].dev; p.y = T(o.out);
                 p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level]; p.Cp = ti.Cp;
-                p.y_pix_bytes = to.Cp * 4; p.y_c0 = o.c0; p.relu = o.relu;
-                rc = esa::launch_cbam_apply(p, stream);
+                p.y_pix_bytes = to.Cp * 4; p.y_c0 = o.c0; p.relu = o.relu; p.C = o.nchan;
+                rc = cbam_fused(ti.Cp, p.H, p.W) ? esa::launch_cbam_spatial(p, stream) : esa::launch_cbam_apply(p, stream);
                 break;
             }
             case OP_RESAMPLE: {
@@ -1854,6 +1864,11 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                                           "resample_slice", "zero_slice", "sb_to_nchw", "head_gather"};
             snprintf(out->kernel, sizeof out->kernel, "%s", names[o.kind - OP_STEMRAW]);
             snprintf(out->label, sizeof out->label, "seg_hrnet3");
+            if ((o.kind == OP_MAPS || o.kind == OP_APPLY) &&
+                cbam_fused(h->tensors[o.in].Cp, lh[h->tensors[o.in].level], lw[h->tensors[o.in].level])) {
+                if (o.kind == OP_MAPS) { out->kernel[0] = 0; snprintf(out->label, sizeof out->label, "(inside cbam_spatial)"); break; }
+                snprintf(out->kernel, sizeof out->kernel, "cbam_spatial");
+            }
             out->bytes = (o.in >= 0 ? tbytes(o.in) : 0.0) + (o.out >= 0 ? tbytes(o.out) : 0.0);
             if (o.kind == OP_GATHER) out->bytes += tbytes(o.terms[0]);
             break;
