@@ -20,11 +20,9 @@ namespace {
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
 
 // ---- pool_partial: grid (P, N), 256 threads; thread = (pixel lane pl, channel group c8) ----------
-__global__ __launch_bounds__(256) void pool_partial_kernel(const char* x, float* partial, int HW, int Cp, int P) {
-    __shared__ float ssum[256 * 8];
-    __shared__ float smax[256 * 8];
+__device__ __forceinline__ void pool_partial_body(const char* x, float* partial, int HW, int Cp, int P, int slab, int n,
+                                                  float* ssum, float* smax) {
     const int G = Cp >> 3, PL = 256 / G;
-    const int slab = blockIdx.x, n = blockIdx.y;
     const int S = (HW + P - 1) / P;
     const int p0 = slab * S, p1 = min(HW, p0 + S);
     const int tid = threadIdx.x, pl = tid / G, c8 = tid - pl * G;
@@ -50,12 +48,16 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const char* x, float*
         o[0] = a; o[1] = b;
     }
 }
+__global__ __launch_bounds__(256) void pool_partial_kernel(const char* x, float* partial, int HW, int Cp, int P) {
+    __shared__ float ssum[256 * 8];
+    __shared__ float smax[256 * 8];
+    pool_partial_body(x, partial, HW, Cp, P, (int)blockIdx.x, (int)blockIdx.y, ssum, smax);
+}
 
 // ---- ca_mlp: grid N, 256 threads ----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ca_mlp_kernel(const float* partial, const float* w0, const float* w2,
-                                                     float* ca, int HW, int C, int Cp, int Cr, int P) {
-    __shared__ float avg[512], mx[512], ha[64], hm[64];
-    const int n = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void ca_mlp_body(const float* partial, const float* w0, const float* w2, float* ca, int HW, int C,
+                                            int Cp, int Cr, int P, int n, float* avg, float* mx, float* ha, float* hm) {
+    const int tid = threadIdx.x;
     // finish the pooling: 8 slabs per step so that 8 loads are in flight (one dependent round trip per slab
     // made this kernel 18 us of pure latency); slab order of the sum is kept
     for (int c = tid; c < Cp; c += 256) {
@@ -95,15 +97,19 @@ __global__ __launch_bounds__(256) void ca_mlp_kernel(const float* partial, const
         ca[(size_t)n * Cp + c] = v;
     }
 }
+__global__ __launch_bounds__(256) void ca_mlp_kernel(const float* partial, const float* w0, const float* w2,
+                                                     float* ca, int HW, int C, int Cp, int Cr, int P) {
+    __shared__ float avg[512], mx[512], ha[64], hm[64];
+    ca_mlp_body(partial, w0, w2, ca, HW, C, Cp, Cr, P, (int)blockIdx.x, avg, mx, ha, hm);
+}
 
 // ---- cbam_maps: thread = (pixel, 8-channel group), group fastest -> coalesced 32-B pieces; the G
 // partial (sum, max) of a pixel meet in LDS ------------------------------------------------------------
-__global__ __launch_bounds__(256) void cbam_maps_kernel(const char* x, const float* ca, float* maps, long long npix,
-                                                        int HW, int C, int Cp) {
-    __shared__ float ps[256], pm[256];
+__device__ __forceinline__ void cbam_maps_body(const char* x, const float* ca, float* maps, long long npix, int HW, int C, int Cp,
+                                               long long block, float* ps, float* pm) {
     const int G = Cp >> 3, PPB = 256 / G;                 // pixels per block
     const int tid = threadIdx.x, pl = tid / G, c8 = tid - pl * G;
-    const long long pix = (long long)blockIdx.x * PPB + pl;
+    const long long pix = block * PPB + pl;
     float s = 0.f, m = -INFINITY;
     if (pl < PPB && pix < npix && c8 * 8 < C) {
         const int n = (int)(pix / HW);
@@ -124,17 +130,20 @@ __global__ __launch_bounds__(256) void cbam_maps_kernel(const char* x, const flo
         maps[pix * 2 + 1] = b;
     }
 }
+__global__ __launch_bounds__(256) void cbam_maps_kernel(const char* x, const float* ca, float* maps, long long npix,
+                                                        int HW, int C, int Cp) {
+    __shared__ float ps[256], pm[256];
+    cbam_maps_body(x, ca, maps, npix, HW, C, Cp, (long long)blockIdx.x, ps, pm);
+}
 
 // ---- cbam_apply: thread = (pixel, 8-channel group); the pixel's first thread evaluates the 7x7
 // spatial attention once and shares it through LDS ----------------------------------------------------
-__global__ __launch_bounds__(256) void cbam_apply_kernel(CbamApplyParams p, long long npix) {
-    __shared__ float w[98];
-    __shared__ float sas[256];
+__device__ __forceinline__ void cbam_apply_body(const CbamApplyParams& p, long long npix, long long block, float* w, float* sas) {
     if (threadIdx.x < 98) w[threadIdx.x] = p.w_sa[threadIdx.x];
     __syncthreads();
     const int G = p.Cp >> 3, PPB = 256 / G;
     const int tid = threadIdx.x, pl = tid / G, c8 = tid - pl * G;
-    const long long idx = (long long)blockIdx.x * PPB + pl;
+    const long long idx = block * PPB + pl;
     const bool live = pl < PPB && idx < npix;
     const int HW = p.H * p.W;
     int n = 0;
@@ -188,17 +197,21 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(CbamApplyParams p, long
     *reinterpret_cast<uint4*>(o + 16) = lo;
 }
 
+__global__ __launch_bounds__(256) void cbam_apply_kernel(CbamApplyParams p, long long npix) {
+    __shared__ float w[98];
+    __shared__ float sas[256];
+    cbam_apply_body(p, npix, (long long)blockIdx.x, w, sas);
+}
+
 // ---- cbam_spatial: cbam_maps + cbam_apply in one pass over a 16 x 32 tile (+ 3-pixel halo for the 7x7) -------------
 // The two kernels above read x twice and hand the 2-channel maps through HBM.  Here a workgroup forms the maps of its
 // halo'd tile in LDS (the halo pixels' x comes out of L2: the neighbouring tiles read them too), evaluates the 7x7 spatial
 // attention from there and applies it.  thread = (pixel, 8-channel group), the G = Cp/8 threads of a pixel are
 // neighbouring lanes (G a power of two <= 32): channel reductions and the 49 taps are shared by xor-shuffles.
 constexpr int CS_TH = 16, CS_TW = 32, CS_HH = CS_TH + 6, CS_HW = CS_TW + 6;
-__global__ __launch_bounds__(256) void cbam_spatial_kernel(CbamApplyParams p, int tiles_x, int tiles_y) {
-    __shared__ float mp[CS_HH * CS_HW * 2];
-    __shared__ float w[98];
+__device__ __forceinline__ void cbam_spatial_body(const CbamApplyParams& p, int tiles_x, int tiles_y, int block, float* mp, float* w) {
     const int tid = threadIdx.x;
-    int b = (int)blockIdx.x;
+    int b = block;
     const int tx0 = (b % tiles_x) * CS_TW; b /= tiles_x;
     const int ty0 = (b % tiles_y) * CS_TH;
     const int n = b / tiles_y;
@@ -278,6 +291,34 @@ __global__ __launch_bounds__(256) void cbam_spatial_kernel(CbamApplyParams p, in
         char* o = p.y + idx * (size_t)p.y_pix_bytes + ((p.y_c0 >> 3) + lg) * 32;
         *reinterpret_cast<uint4*>(o) = hi;
         *reinterpret_cast<uint4*>(o + 16) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void cbam_spatial_kernel(CbamApplyParams p, int tiles_x, int tiles_y) {
+    __shared__ float mp[CS_HH * CS_HW * 2];
+    __shared__ float w[98];
+    cbam_spatial_body(p, tiles_x, tiles_y, (int)blockIdx.x, mp, w);
+}
+
+// ---- the same launches for several tensors at once: the CBAM blocks of the branches of an HRModule at one depth are
+// independent (seg_hrnet3.py: every branch is its own Sequential of BasicBlocks), and on the 32x32 and 16x16 branches each of
+// these kernels is a few microseconds of pure launch latency.  Workgroups [start[j], start[j+1]) run job j exactly as its own
+// launch would. ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cbam_jobs_kernel(CbamJobs jobs) {
+    __shared__ float sh[4096];
+    __shared__ float sw[128];
+    const int b = (int)blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < CBAM_MAXJOBS; ++k) j += (k < jobs.n && b >= jobs.start[k]) ? 1 : 0;
+    const CbamJob& q = jobs.j[j];
+    const int bid = b - jobs.start[j];
+    switch (q.kind) {
+        case CBAM_POOL: pool_partial_body(q.ap.x, q.partial, q.HW, q.ap.Cp, q.P, bid % q.P, bid / q.P, sh, sh + 2048); break;
+        case CBAM_MLP: ca_mlp_body(q.partial, q.w0, q.w2, q.ca, q.HW, q.ap.C, q.ap.Cp, q.Cr, q.P, bid, sh, sh + 512, sh + 1024, sh + 1088); break;
+        case CBAM_MAPS: cbam_maps_body(q.ap.x, q.ap.ca, q.maps, (long long)q.ap.N * q.HW, q.HW, q.ap.C, q.ap.Cp, bid, sh, sh + 256); break;
+        case CBAM_APPLY: cbam_apply_body(q.ap, (long long)q.ap.N * q.HW, bid, sw, sh); break;
+        default: cbam_spatial_body(q.ap, q.tiles_x, q.tiles_y, bid, sh, sw); break;
     }
 }
 
@@ -374,6 +415,41 @@ int launch_cbam_apply(const CbamApplyParams& p, hipStream_t s) {
     if ((p.y_c0 & 7) || (p.Cp & 7) || p.Cp > 2048 || p.Cp < 8) return (int)hipErrorInvalidValue;
     const int ppb = 256 / (p.Cp >> 3);
     hipLaunchKernelGGL(cbam_apply_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, s, p, npix);
+    return (int)hipGetLastError();
+}
+
+// workgroups job `q` needs (the grid its own launch would use); -1: invalid
+long long cbam_job_blocks(CbamJob& q) {
+    const int Cp = q.ap.Cp;
+    if ((Cp & 7) || Cp < 8) return -1;
+    switch (q.kind) {
+        case CBAM_POOL: return Cp > 256 ? -1 : (long long)q.P * q.ap.N;
+        case CBAM_MLP: return (Cp > 512 || q.Cr > 64 || q.Cr < 1) ? -1 : q.ap.N;
+        case CBAM_MAPS: { if (Cp > 2048) return -1; const int ppb = 256 / (Cp >> 3); return ((long long)q.ap.N * q.HW + ppb - 1) / ppb; }
+        case CBAM_APPLY: { if (Cp > 2048 || (q.ap.y_c0 & 7)) return -1; const int ppb = 256 / (Cp >> 3); return ((long long)q.ap.N * q.HW + ppb - 1) / ppb; }
+        case CBAM_SPATIAL:
+            if (!cbam_spatial_supported(Cp) || (q.ap.y_c0 & 7) || q.ap.C < 1 || q.ap.C > Cp) return -1;
+            q.tiles_x = (q.ap.W + CS_TW - 1) / CS_TW; q.tiles_y = (q.ap.H + CS_TH - 1) / CS_TH;
+            return (long long)q.tiles_x * q.tiles_y * q.ap.N;
+    }
+    return -1;
+}
+
+int launch_cbam_jobs(const CbamJob* js, int n, hipStream_t s) {
+    if (n < 1 || n > CBAM_MAXJOBS) return (int)hipErrorInvalidValue;
+    CbamJobs jobs{};
+    long long at = 0;
+    for (int k = 0; k < n; ++k) {
+        jobs.j[k] = js[k];
+        const long long nb = cbam_job_blocks(jobs.j[k]);
+        if (nb <= 0) return (int)hipErrorInvalidValue;
+        jobs.start[k] = (int)at;
+        at += nb;
+        if (at > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    }
+    for (int k = n; k <= CBAM_MAXJOBS; ++k) jobs.start[k] = (int)at;
+    jobs.n = n;
+    hipLaunchKernelGGL(cbam_jobs_kernel, dim3((unsigned)at), dim3(256), 0, s, jobs);
     return (int)hipGetLastError();
 }
 

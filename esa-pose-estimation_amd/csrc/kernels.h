@@ -210,6 +210,20 @@ int launch_cbam_apply(const CbamApplyParams& p, hipStream_t s);
 // maps + apply in one pass (no `maps` tensor); Cp / 8 must be a power of two <= 32
 bool cbam_spatial_supported(int Cp);
 int launch_cbam_spatial(const CbamApplyParams& p, hipStream_t s);
+// one launch for the same CBAM step of up to four tensors (the branches of an HRModule at one depth)
+enum { CBAM_POOL = 0, CBAM_MLP = 1, CBAM_MAPS = 2, CBAM_APPLY = 3, CBAM_SPATIAL = 4 };
+constexpr int CBAM_MAXJOBS = 4;
+struct CbamJob {
+    int kind;
+    CbamApplyParams ap;         // every kind: x, N, H, W, Cp, C (+ the rest for APPLY / SPATIAL; ca for MAPS)
+    float* partial;             // POOL (out), MLP (in)
+    const float* w0; const float* w2; float* ca;        // MLP
+    float* maps;                // MAPS (out)
+    int HW, P, Cr;
+    int tiles_x, tiles_y;       // filled by the launcher
+};
+struct CbamJobs { CbamJob j[CBAM_MAXJOBS]; int start[CBAM_MAXJOBS + 1]; int n; };
+int launch_cbam_jobs(const CbamJob* jobs, int n, hipStream_t s);
 struct ResampleParams {
     const char* x;      // SB [N][h][w][Cp_src]
     char* y;            // SB [N][H][W][..], pixel pitch y_pix_bytes, channel offset y_c0 (multiple of 8)

@@ -421,6 +421,9 @@ void group_jobs(esahrnet_ctx& c) {
     if (getenv("ESAHRNET_NO_JOBS")) return;
     std::vector<Op> ops = c.ops;
     auto eligible = [&](const Op& o) {
+        // the CBAM launches of a depth (seg_hrnet3): same kind on every branch, one launch (cbam.hip: cbam_jobs_kernel)
+        if ((o.kind == OP_POOL || o.kind == OP_MLP || o.kind == OP_MAPS || o.kind == OP_APPLY) && o.jkey >= 0)
+            return !getenv("ESAHRNET_NO_CBAM_JOBS");
         if (o.kind != OP_CONV || o.jkey < 0 || o.alt != 0 || o.multi >= 0) return false;
         const DevConv& d = c.dconvs[o.dconv];
         const ConvSpec& s = c.specs[d.spec];
@@ -945,6 +948,7 @@ esa::ConvParams conv_params_of(const esahrnet_ctx& c, const Op& o, int n, const 
 // is this job group evaluated as ONE launch at this shape?  Every member must be a stream-kernel launch of its own
 // there (the kernel serving a layer depends on the shape only, never on the grouping)
 bool job_on_for(const esahrnet_ctx& c, const JobGroup& g, int n, const std::vector<int>& lh, const std::vector<int>& lw) {
+    if (c.ops[g.op[0]].kind != OP_CONV) return true;        // CBAM groups: the merged kernel runs every shape its members run
     esa::ConvParams ps[6];
     if (c.specs[c.dconvs[c.ops[g.op[0]].dconv].spec].k == 1) {
         for (int k = 0; k < g.n; ++k) ps[k] = conv_params_of(c, c.ops[g.op[k]], n, lh, lw, nullptr);
@@ -1393,6 +1397,36 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
         return 0;
     };
     const int active_alt = sp.head2 ? 2 : 1;
+    // one CBAM launch as a job description (cbam.hip); kind < 0: nothing to launch (maps formed inside cbam_spatial)
+    auto cbam_job = [&](const Op& o) {
+        esa::CbamJob q{};
+        q.kind = -1;
+        const Tensor& tx = h->tensors[o.kind == OP_MLP ? o.terms[0] : o.in];
+        const int hh = sp.lh[tx.level], ww = sp.lw[tx.level];
+        q.ap.N = n; q.ap.H = hh; q.ap.W = ww; q.ap.Cp = tx.Cp; q.ap.C = o.nchan;
+        q.HW = hh * ww; q.P = std::min(Builder::POOL_SLABS, q.HW); q.Cr = o.nchan / 16;
+        switch (o.kind) {
+            case OP_POOL: q.kind = esa::CBAM_POOL; q.ap.x = T(o.in); q.partial = reinterpret_cast<float*>(T(o.out)); q.ap.C = tx.C; break;
+            case OP_MLP:
+                q.kind = esa::CBAM_MLP; q.partial = reinterpret_cast<float*>(T(o.in)); q.ca = reinterpret_cast<float*>(T(o.out));
+                q.w0 = h->aux[o.aux[0]].dev; q.w2 = h->aux[o.aux[1]].dev;
+                break;
+            case OP_MAPS:
+                if (cbam_fused(tx.Cp, hh, ww)) break;
+                q.kind = esa::CBAM_MAPS; q.ap.x = T(o.in); q.ap.ca = reinterpret_cast<const float*>(T(o.terms[1]));
+                q.maps = reinterpret_cast<float*>(T(o.out));
+                break;
+            default: {
+                const Tensor& to = h->tensors[o.out];
+                q.kind = cbam_fused(tx.Cp, hh, ww) ? esa::CBAM_SPATIAL : esa::CBAM_APPLY;
+                q.ap.x = T(o.in); q.ap.res = o.res >= 0 ? T(o.res) : nullptr;
+                q.ap.ca = reinterpret_cast<const float*>(T(o.terms[1])); q.ap.maps = reinterpret_cast<const float*>(T(o.terms[2]));
+                q.ap.w_sa = h->aux[o.aux[2]].dev; q.ap.y = T(o.out);
+                q.ap.y_pix_bytes = to.Cp * 4; q.ap.y_c0 = o.c0; q.ap.relu = o.relu;
+            }
+        }
+        return q;
+    };
     for (const Op& o : h->ops) {
         int rc = 0;
         if (multi) {
@@ -1427,6 +1461,20 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 rc = esa::launch_stem(p, stream);
                 break;
             }
+            case OP_POOL: case OP_MLP: case OP_MAPS: case OP_APPLY:
+                if (o.job >= 0 && sp.job_on[o.job]) {           // the same step of every branch of the module in one launch
+                    if (o.jpos > 0) break;
+                    const JobGroup& g = h->jobs[o.job];
+                    esa::CbamJob js[esa::CBAM_MAXJOBS];
+                    int nj = 0;
+                    for (int k = 0; k < g.n; ++k) {
+                        const esa::CbamJob q = cbam_job(h->ops[g.op[k]]);
+                        if (q.kind >= 0) js[nj++] = q;
+                    }
+                    if (nj) rc = esa::launch_cbam_jobs(js, nj, stream);
+                    break;
+                }
+                switch (o.kind) {
             case OP_POOL: {
                 const Tensor& ti = h->tensors[o.in];
                 const int HW = sp.lh[ti.level] * sp.lw[ti.level];
@@ -1462,6 +1510,9 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 rc = cbam_fused(ti.Cp, p.H, p.W) ? esa::launch_cbam_spatial(p, stream) : esa::launch_cbam_apply(p, stream);
                 break;
             }
+            default: break;
+                }                   // (inner switch: the single-tensor launches)
+                break;
             case OP_RESAMPLE: {
                 const Tensor& ti = h->tensors[o.in];
                 const Tensor& to = h->tensors[o.out];
@@ -1864,12 +1915,34 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                                           "resample_slice", "zero_slice", "sb_to_nchw", "head_gather"};
             snprintf(out->kernel, sizeof out->kernel, "%s", names[o.kind - OP_STEMRAW]);
             snprintf(out->label, sizeof out->label, "seg_hrnet3");
+            if (o.job >= 0 && (o.kind == OP_POOL || o.kind == OP_MLP || o.kind == OP_MAPS || o.kind == OP_APPLY)) {
+                // merged launch of the group (run_forward): issued at the first member, for every member that launches at all
+                const JobGroup& g = h->jobs[o.job];
+                auto folded = [&](const Op& ok) {
+                    return ok.kind == OP_MAPS && cbam_fused(h->tensors[ok.in].Cp, lh[h->tensors[ok.in].level], lw[h->tensors[ok.in].level]);
+                };
+                int launching = 0;
+                for (int k = 0; k < g.n; ++k) launching += folded(h->ops[g.op[k]]) ? 0 : 1;
+                if (o.jpos > 0 || launching == 0) {
+                    out->kernel[0] = 0;
+                    snprintf(out->label, sizeof out->label, "seg_hrnet3 (%s)", launching ? "in the merged launch" : "inside cbam_spatial");
+                    break;
+                }
+                static const char* jn[] = {"cbam_jobs(pool)", "cbam_jobs(mlp)", "cbam_jobs(maps)", "cbam_jobs(apply)"};
+                snprintf(out->kernel, sizeof out->kernel, "%s", jn[o.kind - OP_POOL]);
+                snprintf(out->label, sizeof out->label, "seg_hrnet3: %d branches", launching);
+                for (int k = 0; k < g.n; ++k) {
+                    const Op& ok = h->ops[g.op[k]];
+                    if (!folded(ok)) out->bytes += (ok.in >= 0 ? tbytes(ok.in) : 0.0) + (ok.out >= 0 ? tbytes(ok.out) : 0.0);
+                }
+                break;
+            }
             if ((o.kind == OP_MAPS || o.kind == OP_APPLY) &&
                 cbam_fused(h->tensors[o.in].Cp, lh[h->tensors[o.in].level], lw[h->tensors[o.in].level])) {
                 if (o.kind == OP_MAPS) { out->kernel[0] = 0; snprintf(out->label, sizeof out->label, "(inside cbam_spatial)"); break; }
                 snprintf(out->kernel, sizeof out->kernel, "cbam_spatial");
             }
-            out->bytes = (o.in >= 0 ? tbytes(o.in) : 0.0) + (o.out >= 0 ? tbytes(o.out) : 0.0);
+            out->bytes += (o.in >= 0 ? tbytes(o.in) : 0.0) + (o.out >= 0 ? tbytes(o.out) : 0.0);
             if (o.kind == OP_GATHER) out->bytes += tbytes(o.terms[0]);
             break;
         }
