@@ -370,7 +370,10 @@ class _Runtime:
         ws.record_stream(ts)
         x.record_stream(ts)
         if nt:
-            heat._esa_partials = (part, nt, heat._version)
+            try:
+                heat._esa_partials = (part, nt, heat._version)
+            except RuntimeError:            # torch.inference_mode(): no version counter, so no way to tell a later edit
+                pass
         return heat
 
     def _partial_tiles(self, h, hh, ww):

@@ -32,8 +32,13 @@ def _keypoints(heat: torch.Tensor, want_index: bool):
     # (hrnet._Runtime.forward): finishing over those gives the same bits without reading the maps again.  The note is
     # honoured only for this very tensor object, unmodified since (views, clones and in-place edits take the full sweep).
     note = getattr(heat, "_esa_partials", None)
-    if note is not None and (note[2] != heat._version or not heat.is_contiguous() or note[0].device != heat.device):
-        note = None
+    if note is not None:
+        try:
+            fresh = note[2] == heat._version
+        except RuntimeError:                # inference tensor: no version counter
+            fresh = False
+        if not fresh or not heat.is_contiguous() or note[0].device != heat.device:
+            note = None
     heat = heat.contiguous()
     n, k, h, w = heat.shape
     kp = torch.empty((n, k, 3), dtype=torch.float32, device=heat.device)

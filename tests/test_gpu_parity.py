@@ -536,6 +536,11 @@ def test_keypoints_from_tile_maxima_equal_the_full_sweep(env, shape):
         heat[0, 0, 5, 7] = 1e9
         kp_edit = inf.heatmaps_to_keypoints(heat)
     assert kp_edit[0, 0, 2].item() == 1e9 and abs(kp_edit[0, 0, 0].item() - 7) < 1 and abs(kp_edit[0, 0, 1].item() - 5) < 1
+    # torch.inference_mode(): tensors carry no version counter -> no note, full sweep, same result
+    with torch.inference_mode():
+        heat_i = net(x)
+        kp_i = inf.heatmaps_to_keypoints(heat_i)
+    assert getattr(heat_i, "_esa_partials", None) is None and torch.equal(kp_i, kp_fast)
     # ties: zero weights in the output layer -> every plane is the constant bias -> first index (0, 0)
     sd0 = {k: v.clone() for k, v in sd.items()}
     sd0["output_layer.0.weight"].zero_()
