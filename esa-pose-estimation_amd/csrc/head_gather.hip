@@ -51,9 +51,12 @@ __device__ __host__ inline Lerp1 lerp_half(int dst, int in, int out) {
 // for positions outside the image (the convolution's zero padding)
 struct Samp { int o0, o1; float l0, l1; };
 constexpr int GT_T = 512;        // threads per workgroup: 16 rows of 32 columns
-constexpr int GT_MAXP = 6;      // staged 16-byte pieces a thread may hold for the next channel group
+// GT_MAXP (template): staged 16-byte pieces a thread may hold for the next channel group — 6 (170 window pixels, 127 VGPRs: four
+// waves per SIMD) for every power-of-two crop, 8 (227 pixels, 141 VGPRs) for odd level sizes whose windows are larger
 
-__global__ __launch_bounds__(GT_T, 2) void head_gather_kernel(GatherParams p, int tiles_x, int tiles_y) {
+// (HIP's second launch-bound argument is waves per SIMD: 4 = two 8-wave workgroups per CU = at most 128 VGPRs)
+template <int GT_MAXP>
+__global__ __launch_bounds__(GT_T, GT_MAXP <= 6 ? 4 : 2) void head_gather_kernel(GatherParams p, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     int t = (int)blockIdx.x;
@@ -230,8 +233,9 @@ bool head_gather_supported(int H, int W, const int* h, const int* w, int Cp) {
     for (int i = 0; i < 2; ++i) { p.h[i] = h[i]; p.w[i] = w[i]; }
     if (H < 1 || W < 1 || h[0] < 1 || h[1] < 1 || w[0] < 1 || w[1] < 1 || (Cp & 7)) return false;
     fill_windows(p);
-    // two workgroups per CU, and the staged window must fit the registers a thread stages the next group through
-    return gather_lds(p) <= 80 * 1024 && (p.R[0] * p.Cc[0] + p.R[1] * p.Cc[1]) * 18 <= GT_MAXP * GT_T;
+    // the windows must fit the LDS of a CU (two workgroups per CU up to 80 KB: every power-of-two crop; odd level sizes with
+    // ratios a little under 4 / 8 need up to ~105 KB and run one per CU) and the registers the next group is staged through
+    return gather_lds(p) <= 150 * 1024 && (p.R[0] * p.Cc[0] + p.R[1] * p.Cc[1]) * 18 <= 8 * GT_T;
 }
 
 int launch_head_gather(GatherParams p, hipStream_t stream) {
@@ -242,11 +246,16 @@ int launch_head_gather(GatherParams p, hipStream_t stream) {
     p.gpw = 6;
     const int tiles_x = (p.W + GT_W - 1) / GT_W, tiles_y = (p.H + GT_H - 1) / GT_H;
     const size_t lds = gather_lds(p);
-    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(head_gather_kernel), lds)) return e_;
     const long long nblk = (long long)tiles_x * tiles_y * p.N;
     if (nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(head_gather_kernel, dim3((unsigned)nblk, (unsigned)((p.ngroups + p.gpw - 1) / p.gpw)), dim3(GT_T), lds, stream,
-                       p, tiles_x, tiles_y);
+    const dim3 grid((unsigned)nblk, (unsigned)((p.ngroups + p.gpw - 1) / p.gpw));
+    if ((p.R[0] * p.Cc[0] + p.R[1] * p.Cc[1]) * 18 <= 6 * GT_T) {
+        if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(head_gather_kernel<6>), lds)) return e_;
+        hipLaunchKernelGGL(head_gather_kernel<6>, grid, dim3(GT_T), lds, stream, p, tiles_x, tiles_y);
+    } else {
+        if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(head_gather_kernel<8>), lds)) return e_;
+        hipLaunchKernelGGL(head_gather_kernel<8>, grid, dim3(GT_T), lds, stream, p, tiles_x, tiles_y);
+    }
     return (int)hipGetLastError();
 }
 

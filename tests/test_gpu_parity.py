@@ -480,7 +480,7 @@ def test_hrnet3_intermediates_match_oracle(env):
     assert (taps["heatmaps"].cpu() - out_ref).abs().max().item() <= GUARD
 
 
-@pytest.mark.parametrize("hw", [(70, 50), (16, 16), (36, 132), (128, 128)])
+@pytest.mark.parametrize("hw", [(70, 50), (16, 16), (18, 18), (22, 46), (36, 132), (128, 128), (258, 130)])
 def test_hrnet3_head_by_linearity_matches_oracle_and_direct_form(env, monkeypatch, hw):
     """seg_hrnet3 last_layer[0] (3x3 over the concatenated, up-sampled branches, seg_hrnet3.py:506-515) runs as
     nine 1x1 products on the grids of branches 2 and 3 + head_gather.hip + a direct 3x3 over [branch 0 | up(branch 1)].
