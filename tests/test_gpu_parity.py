@@ -7,6 +7,7 @@ reference CPU forward.  The split-bf16 arithmetic is expected at ~1e-5 (oracle/e
 so the tests assert the contractual 1e-3 AND a tighter 2e-4 regression guard."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -551,6 +552,16 @@ def test_keypoints_from_tile_maxima_equal_the_full_sweep(env, shape):
         kp0_full = inf.heatmaps_to_keypoints(heat0.clone())
     assert torch.equal(kp0, kp0_full)
     assert (kp0[..., :2] == 0).all()
+
+
+def test_every_legal_crop_size_runs(env):
+    """check_shape accepts every even crop size >= 16 (seg_hrnet.py:330,469): a sweep of 47 (height, width) pairs with odd level
+    sizes, tile remainders, tiny and large crops must launch and give finite heat-maps and keypoints for the three variants
+    and both precisions (tools/shape_sweep.py; a 258x130 crop once failed a kernel's window limit)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import shape_sweep
+    msgs = []
+    assert shape_sweep.run(log=lambda *a: msgs.append(" ".join(str(v) for v in a))) == 0, msgs
 
 
 # ------------------------------------------------------------------------------------- boundary (round 2)
