@@ -31,6 +31,11 @@ constexpr int BR1 = 11, BR2 = 7, BR3 = 5;           // max source-region edge pe
 constexpr int BREG = BR1 * BR1 + BR2 * BR2 + BR3 * BR3;   // 195 pixels
 constexpr int BBUF = ((BREG * BPIX + 255) / 256) * 256;
 constexpr int BTHREADS = 64 * BHY;
+// MF (matrix-core interpolation, the default): the staged t-tiles are kept TRANSPOSED, T[branch][source row][channel 0..31]
+// [source column], 16 / 8 / 8 columns per row for the three branches, so that 8 consecutive source columns of one channel
+// are one 16-byte A-operand piece; see the kernel
+constexpr int T1OFF = 0, T2OFF = BR1 * 32 * 16 * 2, T3OFF = T2OFF + BR2 * 32 * 8 * 2, TBYTES = T3OFF + BR3 * 32 * 8 * 2;     // 17 408 B
+static_assert(TBYTES % 256 == 0 && BR1 <= 16 && BR2 <= 8 && BR3 <= 8, "T layout");
 
 struct LerpB {
     int i0, i1;
@@ -48,11 +53,18 @@ __device__ __forceinline__ LerpB lerp_false_b(int dst, int in, int out) {     //
     return r;
 }
 
-template <int NB0, int M3>
-__global__ __launch_bounds__(BTHREADS, 1) void head_fused_bf_kernel(HeadParams p, int tiles_x, int tiles_y) {
+// MF: sum_b U_b·t_b on the matrix cores.  Bilinear interpolation is linear over source pixels and one output row draws on two
+// source rows per branch, so for the wave's row of 16 pixels  sum_b U_b·t_b = T[ch][64 slots] · U[64 slots][16 px], slots =
+// 2 rows x (16 + 8 + 8) source columns = two K-steps (the scheme of head_fused2.hip for the split format).  U depends on the
+// output row and column only: built once per wave, kept in registers, exact in bf16 for the 2x / 4x / 8x grids (numerators
+// < 256); other ratios carry a lo part (`ulo`: two more MFMAs).  The accumulator is the one W0·x0 already uses.  Replaces 96
+// multiply-adds + 96 bf16 widenings per lane and chunk (the kernel was VALU-bound: 2.65 ms at W48 384x384 batch 64).
+template <int NB0, int M3, bool MF>
+__global__ __launch_bounds__(BTHREADS, MF ? 4 : 1) void head_fused_bf_kernel(HeadParams p, int tiles_x, int tiles_y, int ulo) {
     constexpr int WFR = 2 * NB0 * 2 + M3;               // 1-KB weight fragments per chunk: W0 [m][block][step], W3 [m]
     constexpr int WBYTES = WFR * 1024;
-    constexpr int STRIDE = BBUF + WBYTES;
+    constexpr int TB = MF ? TBYTES : BBUF;
+    constexpr int STRIDE = TB + WBYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int px = lane & 15, q = lane >> 4;
@@ -89,7 +101,23 @@ __global__ __launch_bounds__(BTHREADS, 1) void head_fused_bf_kernel(HeadParams p
             sg = p.t[b] + (((size_t)n * p.th[b] + yy) * p.tw[b] + xx) * (size_t)(p.Ctp * 2) + (tid & 3) * 16;
         }
     }
-    const int lane_lds = (tid >> 2) * BPIX + (tid & 3) * 16;
+    int lane_lds = (tid >> 2) * BPIX + (tid & 3) * 16;
+    int tstride = 0;                            // MF: bytes between consecutive channels of the thread's staged pixel
+    if (MF) {
+        const int s_ = tid >> 2;
+        if (s_ < npix_stage) {
+            const int b = s_ >= rbase[2] ? 2 : (s_ >= rbase[1] ? 1 : 0);
+            const int r = s_ - rbase[b];
+            const int row = r / rw[b], col = r % rw[b];
+            const int cw = b == 0 ? 16 : 8;
+            tstride = cw * 2;
+            lane_lds = (b == 0 ? T1OFF : b == 1 ? T2OFF : T3OFF) + ((row * 32 + (tid & 3) * 8) * cw + col) * 2;
+        }
+        // columns beyond a window keep their zeros (their U entries are zero, but 0 x stale NaN bits would not be)
+        for (int i = tid * 16; i < 2 * STRIDE; i += BTHREADS * 16)
+            if (i % STRIDE < TB) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
     constexpr int WIT = (WFR * 64 + BTHREADS - 1) / BTHREADS;     // weight staging iterations (one fragment per wave each)
     uint4 sr, wreg[WIT];
 #define HB_PREFETCH(CH)                                                                       \
@@ -108,10 +136,19 @@ __global__ __launch_bounds__(BTHREADS, 1) void head_fused_bf_kernel(HeadParams p
     }
 #define HB_COMMIT(BUF)                                                                        \
     {                                                                                         \
-        if (sg) *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + lane_lds) = sr;             \
+        if (MF) {                                                                             \
+            if (sg) {                                                                         \
+                char* d_ = smem + (BUF) * STRIDE + lane_lds;                                  \
+                const uint32_t w_[4] = {sr.x, sr.y, sr.z, sr.w};                              \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) {                               \
+                    *reinterpret_cast<unsigned short*>(d_ + (2 * k) * tstride) = (unsigned short)(w_[k] & 0xffffu);     \
+                    *reinterpret_cast<unsigned short*>(d_ + (2 * k + 1) * tstride) = (unsigned short)(w_[k] >> 16);     \
+                }                                                                             \
+            }                                                                                 \
+        } else if (sg) *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + lane_lds) = sr;      \
         _Pragma("unroll") for (int wi = 0; wi < WIT; ++wi)                                    \
             if (wi * BHY + wave < WFR)                                                        \
-                *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + BBUF + ((wi * BHY + wave) * 64 + lane) * 16) = wreg[wi]; \
+                *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + TB + ((wi * BHY + wave) * 64 + lane) * 16) = wreg[wi]; \
     }
 
     const int ox = ox0 + px, oy = oy0 + wave;
@@ -128,10 +165,52 @@ __global__ __launch_bounds__(BTHREADS, 1) void head_fused_bf_kernel(HeadParams p
         x0[c] = __builtin_bit_cast(bf16x8, h);
         x1[c] = __builtin_bit_cast(bf16x8, l);
     }
-    int o00[3], o01[3], o10[3], o11[3];     // LDS byte offsets of the 4 taps (incl. region base, q*8)
+    // MF: interpolation operand U (B operand: lane = pixel px, k-group q = 8 slots) and the lane's T pieces (A operand:
+    // lane & 15 = channel, k-group q).  K-step 0 = t_1: q = 2 * (row 0/1) + (columns 0-7 / 8-15);  K-step 1: q = 0/1 t_2 row
+    // 0/1, q = 2/3 t_3 row 0/1, columns 0-7.
+    bf16x8 u0 = {}, u1 = {}, u0l = {}, u1l = {};
+    int toff0 = 0, toff1 = 0;
+    if (MF) {
+        float wa[8], wb_[8];
+        const int ch = lane & 15;
+        {
+            const LerpB lx = lerp_false_b(min(ox, p.W - 1), p.tw[0], p.W), ly = lerp_false_b(min(oy, p.H - 1), p.th[0], p.H);
+            const float wr = (q >> 1) ? ly.l1 : ly.l0;
+            const int row = ((q >> 1) ? ly.i1 : ly.i0) - ry0[0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = (q & 1) * 8 + j + rx0[0];
+                wa[j] = wr * ((c == lx.i0 ? lx.l0 : 0.f) + (c == lx.i1 ? lx.l1 : 0.f));
+            }
+            toff0 = T1OFF + ((row * 32 + ch) * 16 + (q & 1) * 8) * 2;
+        }
+        {
+            const int b = 1 + (q >> 1);
+            const LerpB lx = lerp_false_b(min(ox, p.W - 1), p.tw[b], p.W), ly = lerp_false_b(min(oy, p.H - 1), p.th[b], p.H);
+            const float wr = (q & 1) ? ly.l1 : ly.l0;
+            const int row = ((q & 1) ? ly.i1 : ly.i0) - ry0[b];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = j + rx0[b];
+                wb_[j] = wr * ((c == lx.i0 ? lx.l0 : 0.f) + (c == lx.i1 ? lx.l1 : 0.f));
+            }
+            toff1 = (b == 1 ? T2OFF : T3OFF) + ((row * 32 + ch) * 8) * 2;
+        }
+        const uint4 ha = pack8_bf16(wa), hb = pack8_bf16(wb_);
+        u0 = __builtin_bit_cast(bf16x8, ha);
+        u1 = __builtin_bit_cast(bf16x8, hb);
+        float ra[8], rb[8];
+        unpack8_bf16(ha, ra);
+        unpack8_bf16(hb, rb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ra[j] = wa[j] - ra[j]; rb[j] = wb_[j] - rb[j]; }
+        u0l = __builtin_bit_cast(bf16x8, pack8_bf16(ra));
+        u1l = __builtin_bit_cast(bf16x8, pack8_bf16(rb));
+    }
+    int o00[3], o01[3], o10[3], o11[3];     // (VALU form) LDS byte offsets of the 4 taps (incl. region base, q*8)
     float w00[3], w01[3], w10[3], w11[3];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < 3 && !MF; ++b) {
         const LerpB lx = lerp_false_b(min(ox, p.W - 1), p.tw[b], p.W);
         const LerpB ly = lerp_false_b(min(oy, p.H - 1), p.th[b], p.H);
         const int r0 = (rbase[b] + (ly.i0 - ry0[b]) * rw[b]) * BPIX, r1 = (rbase[b] + (ly.i1 - ry0[b]) * rw[b]) * BPIX;
@@ -151,7 +230,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void head_fused_bf_kernel(HeadParams p
         const int buf = cc & 1;
         if (cc + 1 < nchunks) HB_PREFETCH(cc + 1)
         const char* tb = smem + buf * STRIDE;
-        const char* wb = tb + BBUF + lane * 16;
+        const char* wb = tb + TB + lane * 16;
         f32x4 a[2] = {*reinterpret_cast<const f32x4*>(p.bias0 + cc * 32 + q * 4),
                       *reinterpret_cast<const f32x4*>(p.bias0 + cc * 32 + 16 + q * 4)};
 #pragma unroll
@@ -164,8 +243,21 @@ __global__ __launch_bounds__(BTHREADS, 1) void head_fused_bf_kernel(HeadParams p
                 a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1[c], a[m], 0, 0, 0);
             }
         f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (MF) {
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+            for (int m = 0; m < 2; ++m) {
+                const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(tb + toff0 + m * (16 * 16 * 2));
+                const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(tb + toff1 + m * (16 * 8 * 2));
+                a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t0, u0, a[m], 0, 0, 0);
+                a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1, u1, a[m], 0, 0, 0);
+                if (ulo) {
+                    a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t0, u0l, a[m], 0, 0, 0);
+                    a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1, u1l, a[m], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 3 && !MF; ++b)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 float v00[4], v01[4], v10[4], v11[4];
@@ -215,15 +307,18 @@ __global__ __launch_bounds__(BTHREADS, 1) void head_fused_bf_kernel(HeadParams p
     }
 }
 
-template <int NB0, int M3>
+template <int NB0, int M3, bool MF>
 int launch_head_bf_t(const HeadParams& p, hipStream_t stream) {
-    auto kern = head_fused_bf_kernel<NB0, M3>;
-    const int lds = 2 * (BBUF + (2 * NB0 * 2 + M3) * 1024);
+    auto kern = head_fused_bf_kernel<NB0, M3, MF>;
+    const int lds = 2 * ((MF ? TBYTES : BBUF) + (2 * NB0 * 2 + M3) * 1024);
+    // exact bf16 interpolation weights: every branch grid is the 2x / 4x / 8x decimation of branch 0's
+    int ulo = 0;
+    for (int b = 0; b < 3; ++b) ulo |= (p.th[b] << (b + 1)) != p.H || (p.tw[b] << (b + 1)) != p.W;
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const int tiles_x = (p.W + BHT - 1) / BHT, tiles_y = (p.H + BHY - 1) / BHY;
     const long long nblk = (long long)p.N * tiles_x * tiles_y;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BTHREADS), lds, stream, p, tiles_x, tiles_y);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(BTHREADS), lds, stream, p, tiles_x, tiles_y, ulo);
     return (int)hipGetLastError();
 }
 
@@ -244,10 +339,18 @@ bool head_fused_bf_supported(int H, int W, const int th[3], const int tw[3], int
 int launch_head_bf(const HeadParams& p, hipStream_t stream) {
     if ((p.Ctp & 31) || (p.C3p & 3)) return (int)hipErrorInvalidValue;
     const int m3 = p.K <= 16 ? 1 : 2;
-    if (p.C0p == 64 && m3 == 1) return launch_head_bf_t<1, 1>(p, stream);
-    if (p.C0p == 64 && m3 == 2) return launch_head_bf_t<1, 2>(p, stream);
-    if (p.C0p == 128 && m3 == 1) return launch_head_bf_t<2, 1>(p, stream);
-    if (p.C0p == 128 && m3 == 2) return launch_head_bf_t<2, 2>(p, stream);
+    const bool valu = getenv("ESAHRNET_BF_HEAD_VALU") != nullptr;       // the first-generation (VALU interpolation) form (A/B, tests)
+    if (valu) {
+        if (p.C0p == 64 && m3 == 1) return launch_head_bf_t<1, 1, false>(p, stream);
+        if (p.C0p == 64 && m3 == 2) return launch_head_bf_t<1, 2, false>(p, stream);
+        if (p.C0p == 128 && m3 == 1) return launch_head_bf_t<2, 1, false>(p, stream);
+        if (p.C0p == 128 && m3 == 2) return launch_head_bf_t<2, 2, false>(p, stream);
+        return (int)hipErrorInvalidValue;
+    }
+    if (p.C0p == 64 && m3 == 1) return launch_head_bf_t<1, 1, true>(p, stream);
+    if (p.C0p == 64 && m3 == 2) return launch_head_bf_t<1, 2, true>(p, stream);
+    if (p.C0p == 128 && m3 == 1) return launch_head_bf_t<2, 1, true>(p, stream);
+    if (p.C0p == 128 && m3 == 2) return launch_head_bf_t<2, 2, true>(p, stream);
     return (int)hipErrorInvalidValue;
 }
 

@@ -206,6 +206,26 @@ def test_bf16_odd_shapes_match_emulation(env, hw):
     assert (y - emu).abs().max().item() <= TOL_EMU
 
 
+@pytest.mark.parametrize("hw", [(128, 128), (104, 72), (70, 50)])
+def test_bf16_head_interpolation_on_matrix_cores_matches_valu_form(env, monkeypatch, hw):
+    """head_fused_bf.hip evaluates sum_b up(t_b) as T . U on the matrix cores (U = interpolation weights: exact in bf16 for the
+    2x / 4x / 8x grids, hi + lo otherwise — 104x72 and 70x50 have branch grids that are not exact decimations).  The first
+    form (four VALU taps per branch, ESAHRNET_BF_HEAD_VALU=1) computes the same sums in another order: the two must agree
+    to the rounding of h0 to bf16."""
+    net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 8)
+    x = env["synth"].make_crops(2, 1, hw[0], hw[1], seed=8).cuda()
+    with torch.no_grad():
+        monkeypatch.delenv("ESAHRNET_BF_HEAD_VALU", raising=False)
+        y_mf, ops = net.forward_timed(x)
+        monkeypatch.setenv("ESAHRNET_BF_HEAD_VALU", "1")
+        y_valu = net(x)
+    if "head_fused_bf" not in {o["kernel"] for o in ops}:
+        pytest.skip("this geometry runs the unfused head alternative")
+    scale = max(1.0, y_valu.abs().max().item())
+    assert (y_mf - y_valu).abs().max().item() <= 4e-3 * scale
+    assert (y_mf - y_valu).abs().mean().item() <= 4e-4 * scale
+
+
 def test_bf16_w48_384_config3(env):
     """BASELINE configs[3]: HRNet-W48 (48/96/192/384), 384x384, bf16 — n = 2 against the emulation and the fp32
     oracle, then the batch-64 workload itself through size-independent properties (crops are independent: every
