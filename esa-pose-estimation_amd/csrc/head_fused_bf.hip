@@ -17,6 +17,8 @@
 //       fragment under the permuted K order pack_head_w3_bf gives W3, so h0 goes straight back into the matrix core.
 // Staging of chunk c+1 (global -> registers) is issued before the math of chunk c and written to the other LDS buffer
 // after it.  Unpinned against the reference by itself; the bf16 network tests cover it (tests/test_gpu_bf16.py).
+#include <algorithm>
+
 #include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
@@ -41,16 +43,25 @@ struct LerpB {
     int i0, i1;
     float l0, l1;
 };
-__device__ __forceinline__ LerpB lerp_false_b(int dst, int in, int out) {     // align_corners=False (ATen)
+__device__ __host__ inline LerpB lerp_false_b(int dst, int in, int out) {     // align_corners=False (ATen)
+#pragma clang fp contract(off)      // host (window limits) and device must see the same source indices: no fma here
     const float scale = (float)in / (float)out;
     float src = scale * ((float)dst + 0.5f) - 0.5f;
     src = src < 0.f ? 0.f : src;
     LerpB r;
-    r.i0 = min((int)src, in - 1);
+    r.i0 = (int)src < in - 1 ? (int)src : in - 1;
     r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
     r.l1 = src - (float)r.i0;
     r.l0 = 1.f - r.l1;
     return r;
+}
+
+// value of lane ^ 4 (bit 2 of the lane = `hi`): two DPP row shifts and a select — no trip through the LDS crossbar, which
+// the kernel already saturates (a __shfl_xor is a ds_bpermute)
+__device__ __forceinline__ uint32_t lane_xor4(uint32_t v, bool hi) {
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true);      // row_shl:4: lane i <- lane i + 4
+    const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4: lane i <- lane i - 4
+    return hi ? dn : up;
 }
 
 // MF: sum_b U_b·t_b on the matrix cores.  Bilinear interpolation is linear over source pixels and one output row draws on two
@@ -92,7 +103,13 @@ __global__ __launch_bounds__(BTHREADS, MF ? 4 : 1) void head_fused_bf_kernel(Hea
 
     // staging: thread -> (staged pixel s = tid >> 2, 16-byte piece j = tid & 3 of the chunk's 64 bytes)
     const char* sg = nullptr;
-    {
+    bool twrite = false;                        // MF: this lane writes its pair's four dwords
+    int pbase[3] = {0, 0, 0}, npairs = 0;       // MF: column pairs per branch region
+    if (MF) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { pbase[b] = npairs; npairs += rh[b] * ((rw[b] + 1) >> 1); }
+    }
+    if (!MF) {
         const int s_ = tid >> 2;
         if (s_ < npix_stage) {
             const int b = s_ >= rbase[2] ? 2 : (s_ >= rbase[1] ? 1 : 0);
@@ -104,14 +121,20 @@ __global__ __launch_bounds__(BTHREADS, MF ? 4 : 1) void head_fused_bf_kernel(Hea
     int lane_lds = (tid >> 2) * BPIX + (tid & 3) * 16;
     int tstride = 0;                            // MF: bytes between consecutive channels of the thread's staged pixel
     if (MF) {
-        const int s_ = tid >> 2;
-        if (s_ < npix_stage) {
-            const int b = s_ >= rbase[2] ? 2 : (s_ >= rbase[1] ? 1 : 0);
-            const int r = s_ - rbase[b];
-            const int row = r / rw[b], col = r % rw[b];
+        // thread = (column pair u = tid >> 3, column of the pair hc = bit 2, 16-byte piece j = tid & 3 = channels 8j .. 8j+7):
+        // the two lanes of a pair swap halves (commit) so that each writes FOUR dwords [even column | odd column] — channels
+        // 8j .. 8j+3 by the even-column lane, 8j+4 .. 8j+7 by the odd-column one — instead of eight 2-byte pieces
+        const int u = tid >> 3, hc = (tid >> 2) & 1;
+        if (u < npairs) {
+            const int b = u >= pbase[2] ? 2 : (u >= pbase[1] ? 1 : 0);
+            const int r = u - pbase[b], pw = (rw[b] + 1) >> 1;
+            const int row = r / pw, cp = r % pw, col = 2 * cp + hc;
             const int cw = b == 0 ? 16 : 8;
             tstride = cw * 2;
-            lane_lds = (b == 0 ? T1OFF : b == 1 ? T2OFF : T3OFF) + ((row * 32 + (tid & 3) * 8) * cw + col) * 2;
+            twrite = true;
+            lane_lds = (b == 0 ? T1OFF : b == 1 ? T2OFF : T3OFF) + ((row * 32 + (tid & 3) * 8 + 4 * hc) * cw + 2 * cp) * 2;
+            if (col < rw[b])
+                sg = p.t[b] + (((size_t)n * p.th[b] + ry0[b] + row) * p.tw[b] + rx0[b] + col) * (size_t)(p.Ctp * 2) + (tid & 3) * 16;
         }
         // columns beyond a window keep their zeros (their U entries are zero, but 0 x stale NaN bits would not be)
         for (int i = tid * 16; i < 2 * STRIDE; i += BTHREADS * 16)
@@ -137,13 +160,16 @@ __global__ __launch_bounds__(BTHREADS, MF ? 4 : 1) void head_fused_bf_kernel(Hea
 #define HB_COMMIT(BUF)                                                                        \
     {                                                                                         \
         if (MF) {                                                                             \
-            if (sg) {                                                                         \
+            const bool hc_ = (tid >> 2) & 1;                                                  \
+            const uint32_t r0_ = lane_xor4(hc_ ? sr.x : sr.z, hc_), r1_ = lane_xor4(hc_ ? sr.y : sr.w, hc_);    \
+            const uint32_t e0_ = hc_ ? r0_ : sr.x, e1_ = hc_ ? r1_ : sr.y;                    \
+            const uint32_t o0_ = hc_ ? sr.z : r0_, o1_ = hc_ ? sr.w : r1_;                    \
+            if (twrite) {                                                                     \
                 char* d_ = smem + (BUF) * STRIDE + lane_lds;                                  \
-                const uint32_t w_[4] = {sr.x, sr.y, sr.z, sr.w};                              \
-                _Pragma("unroll") for (int k = 0; k < 4; ++k) {                               \
-                    *reinterpret_cast<unsigned short*>(d_ + (2 * k) * tstride) = (unsigned short)(w_[k] & 0xffffu);     \
-                    *reinterpret_cast<unsigned short*>(d_ + (2 * k + 1) * tstride) = (unsigned short)(w_[k] >> 16);     \
-                }                                                                             \
+                *reinterpret_cast<uint32_t*>(d_) = (e0_ & 0xffffu) | (o0_ << 16);             \
+                *reinterpret_cast<uint32_t*>(d_ + tstride) = (e0_ >> 16) | (o0_ & 0xffff0000u);       \
+                *reinterpret_cast<uint32_t*>(d_ + 2 * tstride) = (e1_ & 0xffffu) | (o1_ << 16);       \
+                *reinterpret_cast<uint32_t*>(d_ + 3 * tstride) = (e1_ >> 16) | (o1_ & 0xffff0000u);   \
             }                                                                                 \
         } else if (sg) *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + lane_lds) = sr;      \
         _Pragma("unroll") for (int wi = 0; wi < WIT; ++wi)                                    \
@@ -333,7 +359,20 @@ static inline uint16_t hbf16(float f) {
 
 // geometry: the same source-region bounds as head_fused.hip (branch grids at 1/2, 1/4, 1/8 of branch 0's)
 bool head_fused_bf_supported(int H, int W, const int th[3], const int tw[3], int C0p, int K) {
-    return (C0p == 64 || C0p == 128) && head_fused_supported(H, W, th, tw, 64, K);
+    if (!((C0p == 64 || C0p == 128) && head_fused_supported(H, W, th, tw, 64, K))) return false;
+    // the staging threads of a workgroup must cover a tile's source windows: 64 column pairs (matrix-core form) / 128 pixels
+    // (lerp_false_b is compiled without fma contraction on both sides, so these are the device's own numbers)
+    int rows[3] = {0, 0, 0}, cols[3] = {0, 0, 0};
+    for (int b = 0; b < 3; ++b) {
+        for (int o = 0; o < H; o += BHY)
+            rows[b] = std::max(rows[b], lerp_false_b(std::min(o + BHY - 1, H - 1), th[b], H).i1 - lerp_false_b(o, th[b], H).i0 + 1);
+        for (int o = 0; o < W; o += BHT)
+            cols[b] = std::max(cols[b], lerp_false_b(std::min(o + BHT - 1, W - 1), tw[b], W).i1 - lerp_false_b(o, tw[b], W).i0 + 1);
+    }
+    int pairs = 0, pix = 0;
+    for (int b = 0; b < 3; ++b) { pairs += rows[b] * ((cols[b] + 1) / 2); pix += rows[b] * cols[b]; }
+    return pairs <= BTHREADS / 8 && pix <= BTHREADS / 4 && rows[0] <= BR1 && rows[1] <= BR2 && rows[2] <= BR3 &&
+           cols[0] <= 16 && cols[1] <= 8 && cols[2] <= 8;
 }
 
 int launch_head_bf(const HeadParams& p, hipStream_t stream) {
