@@ -1362,8 +1362,7 @@ int esahrnet_workspace_bytes(esahrnet_handle h, int n, int height, int width, si
 // but 64x64 and smaller lose: too few workgroups, each walking a halo that is mostly padding).  The batch size is
 // deliberately not part of the rule: the kernel serving a layer must not depend on it.
 static bool cbam_fused(int Cp, int hh, int ww) {
-    static const bool off = getenv("ESAHRNET_CBAM_UNFUSED") != nullptr;
-    return !off && esa::cbam_spatial_supported(Cp) && ((hh + 15) / 16) * ((ww + 31) / 32) >= 32;
+    return esa::cbam_spatial_supported(Cp) && ((hh + 15) / 16) * ((ww + 31) / 32) >= 32 && !getenv("ESAHRNET_CBAM_UNFUSED");
 }
 
 static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, int width,

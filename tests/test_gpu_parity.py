@@ -554,6 +554,33 @@ def test_keypoints_from_tile_maxima_equal_the_full_sweep(env, shape):
     assert (kp0[..., :2] == 0).all()
 
 
+def test_hrnet3_cbam_forms_agree(env, monkeypatch):
+    """seg_hrnet3's CBAM steps run merged over the branches of a module (cbam_jobs_kernel) and, at the full-resolution
+    levels, with maps + 7x7 attention + apply in one kernel (cbam_spatial).  One launch per step and branch
+    (ESAHRNET_NO_CBAM_JOBS=1) must give the same bits — the merged kernel runs the same bodies —, the two-kernel form
+    (ESAHRNET_CBAM_UNFUSED=1) the same values to f32 re-association of the channel mean."""
+    x = env["synth"].make_crops(2, 1, 128, 160, seed=13).cuda()
+    for name in ("ESAHRNET_NO_CBAM_JOBS", "ESAHRNET_CBAM_UNFUSED"):
+        monkeypatch.delenv(name, raising=False)
+    net, sd = _build(env, "seg_hrnet3", (32, 64, 128, 256), 13)
+    with torch.no_grad():
+        y, ops = net.forward_timed(x)
+    kernels = {o["kernel"] for o in ops}
+    assert "cbam_spatial" in kernels or "cbam_jobs(apply)" in kernels
+    assert any(k.startswith("cbam_jobs") for k in kernels)
+    monkeypatch.setenv("ESAHRNET_NO_CBAM_JOBS", "1")
+    net1, _ = _build(env, "seg_hrnet3", (32, 64, 128, 256), 13)
+    with torch.no_grad():
+        y1, ops1 = net1.forward_timed(x)
+    assert not any(o["kernel"].startswith("cbam_jobs") for o in ops1)
+    assert torch.equal(y1, y)
+    monkeypatch.setenv("ESAHRNET_CBAM_UNFUSED", "1")
+    with torch.no_grad():
+        y2, ops2 = net1.forward_timed(x)
+    assert "cbam_spatial" not in {o["kernel"] for o in ops2} and "cbam_maps" in {o["kernel"] for o in ops2}
+    assert (y2 - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+
+
 def test_every_legal_crop_size_runs(env):
     """check_shape accepts every even crop size >= 16 (seg_hrnet.py:330,469): a sweep of 47 (height, width) pairs with odd level
     sizes, tile remainders, tiny and large crops must launch and give finite heat-maps and keypoints for the three variants
