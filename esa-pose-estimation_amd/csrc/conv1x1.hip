@@ -73,6 +73,7 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
         const int buf = (cc - c_begin) & 1;
         if (cc + 1 < nchunks) C1_PREFETCH(cc + 1)
         const char* wb = smem + buf * (WFR * 1024) + lane * 16;
+        uint2 pk[2];                                 // BF: the two cout tiles' packed quads, stored together below
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int co = cc * 32 + m * 16 + g * 4;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
                 for (int r = 0; r < 4; ++r) v[r] = relu_opt(v[r], rfl);
             }
             if (BF) {
-                if (valid) *reinterpret_cast<uint2*>(orow + co * 2) = pack4_bf16(v);
+                pk[m] = pack4_bf16(v);
             } else if (p.out_f32) {         // plain f32 NHWC (same pixel pitch): the nine-tap products read by head_gather.hip
                 if (valid) *reinterpret_cast<float4*>(orow + co * 4) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -106,6 +107,16 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
                 const uint4 ch = quad_to_chunk(hi, lo);
                 if (valid) *reinterpret_cast<uint4*>(orow + chunk_ofs(co, g)) = ch;
             }
+        }
+        if (BF) {
+            // A lane holds 8 bytes of each cout tile (couts 4g .. 4g+3).  v_permlane16_swap trades the odd lane rows of the
+            // first tile for the even rows of the second: an even row g then owns couts 4g .. 4g+7 of tile 0, an odd row couts
+            // 4(g-1) .. 4(g-1)+7 of tile 1 — ONE 16-byte store per lane, 64 contiguous bytes per pixel and chunk (the 8-byte
+            // stores left 32-byte pieces: half an HBM burst each).  All lanes execute the swap; only the store is predicated.
+            const auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+            const int cob = cc * 32 + ((g & 1) ? 16 + (g - 1) * 4 : g * 4);
+            if (valid) *reinterpret_cast<uint4*>(orow + cob * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
         if (cc + 1 < nchunks) {
             C1_COMMIT(buf ^ 1)
