@@ -20,36 +20,45 @@ namespace {
 
 // BF (ConvParams::bf): NCH counts 64-channel blocks of 128 bytes; the (hi, lo) fragment pair of a chunk becomes the
 // two K-steps of a block (sb.h), 2 MFMAs instead of 3, and the epilogue packs 4 channels into 8 bytes.
-template <int NCH, bool BF>
+// PG: 16-pixel groups per wave.  With 2 the wave reads every weight fragment once for 32 pixels — twice the MFMAs per barrier
+// and per LDS byte; used for the big bf16 launches, whose chunks are only 4 .. 8 MFMAs deep per group.
+template <int NCH, bool BF, int PG = 1>
 __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long long ntiles, const int tiles_per_row,
                                              const int bid, const int G, const int split = 0, const int nsplit = 1) {
     constexpr int WFR = 4 * NCH;                   // 1-KB weight fragments per 32-cout chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const long long tile = (long long)xcd_contiguous(bid, G) * 4 + wave;
-    const bool live = tile < ntiles;
-    const int k = (int)(tile % tiles_per_row);
-    const long long row = tile / tiles_per_row;                 // n*H + y
-    const int col = k * 16 + i;
-    const bool valid = live && col < p.W;
+    bool valid[PG];
+    size_t pixel[PG];                               // (n*H + y) * W + x of the lane's pixel in group pg
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+        const long long tile = ((long long)xcd_contiguous(bid, G) * 4 + wave) * PG + pg;
+        const int k = (int)(tile % tiles_per_row);
+        const long long row = tile / tiles_per_row;                 // n*H + y
+        const int col = k * 16 + i;
+        valid[pg] = tile < ntiles && col < p.W;
+        pixel[pg] = (size_t)row * p.W + col;
+    }
     // very wide outputs (the nine-tap products of head_gather.hip: 135 chunks) are cut into `nsplit` ranges of 32-cout
     // chunks, one workgroup each: more workgroups than CUs on a 16x16 grid, and a shorter serial chunk loop
     const int per = ((p.Coutp >> 5) + nsplit - 1) / nsplit;
     const int c_begin = split * per, nchunks = min(c_begin + per, p.Coutp >> 5);
 
-    bf16x8 xh[NCH], xl[NCH];
+    bf16x8 xh[PG][NCH], xl[PG][NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        uint4 h = make_uint4(0, 0, 0, 0), l = make_uint4(0, 0, 0, 0);
-        if (valid) {
-            const char* a = p.x + ((size_t)row * p.W + col) * (size_t)(p.Cinp * (BF ? 2 : 4)) + c * 128 + g * (BF ? 16 : 32);
-            h = *reinterpret_cast<const uint4*>(a);
-            l = *reinterpret_cast<const uint4*>(a + (BF ? 64 : 16));
+    for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            uint4 h = make_uint4(0, 0, 0, 0), l = make_uint4(0, 0, 0, 0);
+            if (valid[pg]) {
+                const char* a = p.x + pixel[pg] * (size_t)(p.Cinp * (BF ? 2 : 4)) + c * 128 + g * (BF ? 16 : 32);
+                h = *reinterpret_cast<const uint4*>(a);
+                l = *reinterpret_cast<const uint4*>(a + (BF ? 64 : 16));
+            }
+            xh[pg][c] = __builtin_bit_cast(bf16x8, h);
+            xl[pg][c] = __builtin_bit_cast(bf16x8, l);
         }
-        xh[c] = __builtin_bit_cast(bf16x8, h);
-        xl[c] = __builtin_bit_cast(bf16x8, l);
-    }
 
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
@@ -68,44 +77,55 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
     C1_PREFETCH(c_begin)
     C1_COMMIT(0)
     __syncthreads();
-    char* orow = p.y + ((size_t)row * p.W + col) * (size_t)(p.Coutp * (BF ? 2 : 4));
+    char* orow[PG];
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) orow[pg] = p.y + pixel[pg] * (size_t)(p.Coutp * (BF ? 2 : 4));
     for (int cc = c_begin; cc < nchunks; ++cc) {
         const int buf = (cc - c_begin) & 1;
         if (cc + 1 < nchunks) C1_PREFETCH(cc + 1)
         const char* wb = smem + buf * (WFR * 1024) + lane * 16;
-        uint2 pk[2];                                 // BF: the two cout tiles' packed quads, stored together below
+        uint2 pk[PG][2];                             // BF: the two cout tiles' packed quads, stored together below
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int co = cc * 32 + m * 16 + g * 4;
-            f32x4 d = *reinterpret_cast<const f32x4*>(p.bias + co);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+            f32x4 d[PG];
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) d[pg] = bv;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wb + ((m * NCH + c) * 2 + 0) * 1024);
                 const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wb + ((m * NCH + c) * 2 + 1) * 1024);
-                if (BF) {
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[c], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl[c], d, 0, 0, 0);
-                } else {
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[c], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[c], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[c], d, 0, 0, 0);
+#pragma unroll
+                for (int pg = 0; pg < PG; ++pg) {
+                    if (BF) {
+                        d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[pg][c], d[pg], 0, 0, 0);
+                        d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl[pg][c], d[pg], 0, 0, 0);
+                    } else {
+                        d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[pg][c], d[pg], 0, 0, 0);
+                        d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[pg][c], d[pg], 0, 0, 0);
+                        d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[pg][c], d[pg], 0, 0, 0);
+                    }
                 }
             }
-            float v[4] = {d[0], d[1], d[2], d[3]};
-            {
-                const int rfl = relu_floor(p.relu);          // branch-free (see sb.h)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = relu_opt(v[r], rfl);
-            }
-            if (BF) {
-                pk[m] = pack4_bf16(v);
-            } else if (p.out_f32) {         // plain f32 NHWC (same pixel pitch): the nine-tap products read by head_gather.hip
-                if (valid) *reinterpret_cast<float4*>(orow + co * 4) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                uint2 hi, lo;
-                split4(v, hi, lo);
-                const uint4 ch = quad_to_chunk(hi, lo);
-                if (valid) *reinterpret_cast<uint4*>(orow + chunk_ofs(co, g)) = ch;
+            for (int pg = 0; pg < PG; ++pg) {
+                float v[4] = {d[pg][0], d[pg][1], d[pg][2], d[pg][3]};
+                {
+                    const int rfl = relu_floor(p.relu);          // branch-free (see sb.h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = relu_opt(v[r], rfl);
+                }
+                if (BF) {
+                    pk[pg][m] = pack4_bf16(v);
+                } else if (p.out_f32) {     // plain f32 NHWC (same pixel pitch): the nine-tap products read by head_gather.hip
+                    if (valid[pg]) *reinterpret_cast<float4*>(orow[pg] + co * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    const uint4 ch = quad_to_chunk(hi, lo);
+                    if (valid[pg]) *reinterpret_cast<uint4*>(orow[pg] + chunk_ofs(co, g)) = ch;
+                }
             }
         }
         if (BF) {
@@ -113,10 +133,13 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
             // first tile for the even rows of the second: an even row g then owns couts 4g .. 4g+7 of tile 0, an odd row couts
             // 4(g-1) .. 4(g-1)+7 of tile 1 — ONE 16-byte store per lane, 64 contiguous bytes per pixel and chunk (the 8-byte
             // stores left 32-byte pieces: half an HBM burst each).  All lanes execute the swap; only the store is predicated.
-            const auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
-            const auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
             const int cob = cc * 32 + ((g & 1) ? 16 + (g - 1) * 4 : g * 4);
-            if (valid) *reinterpret_cast<uint4*>(orow + cob * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) {
+                const auto sx = __builtin_amdgcn_permlane16_swap(pk[pg][0].x, pk[pg][1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(pk[pg][0].y, pk[pg][1].y, false, false);
+                if (valid[pg]) *reinterpret_cast<uint4*>(orow[pg] + cob * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
         }
         if (cc + 1 < nchunks) {
             C1_COMMIT(buf ^ 1)
@@ -127,9 +150,9 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
 #undef C1_COMMIT
 }
 
-template <int NCH, bool BF = false>
+template <int NCH, bool BF = false, int PG = 1>
 __global__ __launch_bounds__(256, 2) void conv1x1_kernel(ConvParams p, long long ntiles, int tiles_per_row) {
-    conv1x1_body<NCH, BF>(p, ntiles, tiles_per_row, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y);
+    conv1x1_body<NCH, BF, PG>(p, ntiles, tiles_per_row, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // Several independent 1x1 convolutions in one launch (the fuse-up convolutions of an HRModule, models/seg_hrnet.py:
@@ -159,11 +182,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_jobs_kernel(C1Jobs jobs) {
 
 template <int NCH, bool BF = false>
 int launch_conv1x1_n(const ConvParams& p, hipStream_t stream) {
-    auto kern = conv1x1_kernel<NCH, BF>;
     const int lds = 2 * 4 * NCH * 1024;
-    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const int tiles_per_row = (p.W + 15) / 16;
     const long long ntiles = (long long)p.N * p.H * tiles_per_row;
+    // two 16-pixel groups per wave for the big bf16 launches (same MFMAs in the same order on every accumulator: the result
+    // does not depend on the choice)
+    if constexpr (BF && NCH <= 4) {
+        if (ntiles >= 32LL * device_cus()) {
+            auto kern2 = conv1x1_kernel<NCH, BF, 2>;
+            if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern2), lds)) return e_;
+            const long long nblk2 = (ntiles + 7) / 8;
+            if (nblk2 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+            hipLaunchKernelGGL(kern2, dim3((unsigned)nblk2, 1u), dim3(256), lds, stream, p, ntiles, tiles_per_row);
+            return (int)hipGetLastError();
+        }
+    }
+    auto kern = conv1x1_kernel<NCH, BF>;
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const long long nblk = (ntiles + 3) / 4;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     int nsplit = 1;
