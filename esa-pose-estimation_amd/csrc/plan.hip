@@ -714,7 +714,7 @@ int build_plan_ops(esahrnet_ctx& c) {
         const int l0 = B.spec("last_layer.0", "last_layer.1", tot, tot, 3, 1, 1, true, true);
         const int l3 = B.spec("last_layer.3", "last_layer.4", tot, K, 1, 1, 1, true, true);
         c.spec_final = B.spec("output_layer.0", "", K + sw, K, 3, 1, 0, true, false);
-        int h0;
+        int h0, wide_h0 = 0;
         if (ys.size() == 4 && !c.bf && !getenv("ESAHRNET_HEAD3_DIRECT")) {
             // last_layer[0] by linearity (head_gather.hip): branches 2, 3 as nine 1x1 products on their own grids + a gather,
             // branch 0 and the up-sampled branch 1 as a direct 3x3 that takes the gather's result as its residual
@@ -740,6 +740,16 @@ int build_plan_ops(esahrnet_ctx& c) {
             gop.out = B.tensor(tot, 1, "head_gather");
             B.push(gop);
             h0 = B.conv(l0, cat, gop.out, true, "head0", 0, cd);
+            // 64-cout workgroup slices for the direct convolution: the stream kernel stages an input tile once per 64 instead of
+            // once per 32 couts (480 = 7.5 x 64: the output, its residual and the reader's input are padded to 512 channels,
+            // the padding is exact zeros end to end: zero weights, zero bias, zero residual)
+            if (pad64(tot) != pad32(tot) && !getenv("ESAHRNET_HEAD3_COUT32")) {
+                const int cp = pad64(tot);
+                c.tensors[gop.out].Cp = cp;
+                c.tensors[h0].Cp = cp;
+                c.dconvs[c.ops.back().dconv].coutp = cp;
+                wide_h0 = cp;
+            }
         } else {
             const int cat = B.tensor(tot, 1, "head_cat");
             int off = 0;
@@ -755,6 +765,7 @@ int build_plan_ops(esahrnet_ctx& c) {
             h0 = B.conv(l0, cat, -1, true, "head0");
         }
         const int h3 = B.conv(l3, h0, -1, true, "head3");
+        if (wide_h0) c.dconvs[c.ops.back().dconv].cinp = wide_h0;
         const int cat2 = B.tensor(sw + K, 0, "head_cat2");
         B.cbam("", stem_raw, sw, -1, false, cat2, 0);
         { Op o; o.kind = OP_RESAMPLE; o.in = h3; o.out = cat2; o.terms[0] = cat2; o.c0 = sw; o.nchan = K; o.align = 1; B.push(o); }
