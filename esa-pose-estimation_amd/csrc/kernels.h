@@ -74,6 +74,10 @@ struct StemParams {
     int bf;             // 1: y is a BF tensor (cout = padded channel count, multiple of 64)
 };
 int launch_stem(const StemParams& p, hipStream_t stream);
+// the same convolution + the per-channel (sum, max) of the output over slabs of pixels, in pool_partial's layout
+// [N][slabs][cout][2] (cbam.hip); stem_pool_slabs: slabs per image, 0 = not available (needs cin 1, cout 64)
+int stem_pool_slabs(int cin, int cout, int H, int W);
+int launch_stem_pool(const StemParams& p, float* pool, hipStream_t stream);
 
 // ---- fused BasicBlock of the 32-channel branch (bblock32.hip) -------------------------------------
 struct BlockParams {

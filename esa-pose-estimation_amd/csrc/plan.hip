@@ -51,6 +51,7 @@ int fail(const char* fmt, ...) {
     } while (0)
 
 inline int pad32(int c) { return (c + 31) & ~31; }
+constexpr int STEM_POOL_SLABS_MAX = 1024;   // pooled partials of the raw stem tensor: slabs reserved per image
 inline int pad64(int c) { return (c + 63) & ~63; }
 
 struct ConvSpec {               // one Conv2d of the reference module tree
@@ -102,6 +103,7 @@ struct Op {
     int dconv = -1;             // OP_CONV / OP_STEMF / OP_BLOCK (conv1)
     int dconv2 = -1;            // OP_BLOCK (conv2)
     int in = -1, out = -1, res = -1;
+    int out2 = -1;              // second tensor this op writes (OP_STEMRAW: the pooled partials of its output), allocated with it
     int terms[4] = {-1, -1, -1, -1};
     int nterms = 0;
     bool relu = false;
@@ -196,6 +198,7 @@ struct esahrnet_ctx {
     ShapePlan sp;
     int max_level = 0;
     int nhost_specs = -1;       // specs [nhost_specs, end) are derived (ConvSpec::parent); -1: none
+    int stemraw_partial = -1;   // seg_hrnet3: tensor of the pooled partials of the raw stem output when the stem kernel makes them
     std::vector<Multi> multis;
     std::vector<JobGroup> jobs;
 };
@@ -408,6 +411,7 @@ void group_multihead(esahrnet_ctx& c) {
         const Op& o = c.ops[k];
         if (o.kind == OP_HEAD2) c.head2_op = (int)k;
         if (o.out >= 0 && c.tensors[o.out].def < 0) c.tensors[o.out].def = (int)k;
+        if (o.out2 >= 0 && c.tensors[o.out2].def < 0) c.tensors[o.out2].def = (int)k;
         auto use = [&](int t) { if (t >= 0) c.tensors[t].last = std::max(c.tensors[t].last, (int)k); };
         use(o.in); use(o.res);
         for (int t = 0; t < 4; ++t) use(o.terms[t]);
@@ -465,6 +469,7 @@ void group_jobs(esahrnet_ctx& c) {
         const Op& o = c.ops[k];
         if (o.kind == OP_HEAD2 || o.kind == OP_HEADBF) c.head2_op = (int)k;
         if (o.out >= 0 && c.tensors[o.out].def < 0) c.tensors[o.out].def = (int)k;
+        if (o.out2 >= 0 && c.tensors[o.out2].def < 0) c.tensors[o.out2].def = (int)k;
         auto use = [&](int t) { if (t >= 0) c.tensors[t].last = std::max(c.tensors[t].last, (int)k); };
         use(o.in); use(o.res);
         for (int t = 0; t < 4; ++t) use(o.terms[t]);
@@ -767,7 +772,18 @@ int build_plan_ops(esahrnet_ctx& c) {
         const int h3 = B.conv(l3, h0, -1, true, "head3");
         if (wide_h0) c.dconvs[c.ops.back().dconv].cinp = wide_h0;
         const int cat2 = B.tensor(sw + K, 0, "head_cat2");
+        const int first_cbam_op = (int)c.ops.size();
         B.cbam("", stem_raw, sw, -1, false, cat2, 0);
+        // the pooling over the raw stem tensor rides in the kernel that writes it (stem.hip: launch_stem_pool): that op also
+        // owns the partials, sized for the slabs that kernel makes (one per row piece) instead of pool_partial's 64
+        if (c.ops[first_cbam_op].kind == OP_POOL && c.ops[first_cbam_op].in == stem_raw && !getenv("ESAHRNET_STEM_POOL_SEPARATE"))
+            for (Op& so : c.ops)
+                if (so.kind == OP_STEMRAW) {
+                    const int partial = c.ops[first_cbam_op].out;
+                    so.out2 = partial;
+                    c.tensors[partial].flat = STEM_POOL_SLABS_MAX * c.tensors[stem_raw].Cp * 2;
+                    c.stemraw_partial = partial;
+                }
         { Op o; o.kind = OP_RESAMPLE; o.in = h3; o.out = cat2; o.terms[0] = cat2; o.c0 = sw; o.nchan = K; o.align = 1; B.push(o); }
         if (pad32(sw + K) > sw + ((K + 7) & ~7)) {
             Op o; o.kind = OP_ZERO; o.out = cat2; o.terms[0] = cat2; o.c0 = sw + ((K + 7) & ~7); o.nchan = pad32(sw + K) - o.c0;
@@ -1030,6 +1046,13 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
             const size_t len = bytes_of(c.tensors[o.out]);
             const size_t off = alloc(len);
             c.tensors[o.out].off = off;
+            high = std::max(high, std::max(top, off + len));
+        }
+        if (active && o.out2 >= 0 && !allocated[o.out2]) {
+            allocated[o.out2] = 1;
+            const size_t len = bytes_of(c.tensors[o.out2]);
+            const size_t off = alloc(len);
+            c.tensors[o.out2].off = off;
             high = std::max(high, std::max(top, off + len));
         }
         // a job group runs as ONE launch: what one member reads last must not be handed to another member's output, so a
@@ -1372,6 +1395,14 @@ int esahrnet_workspace_bytes(esahrnet_handle h, int n, int height, int width, si
 // and the image has at least 32 of its 16 x 32 tiles (measured, batch 32: 128x128x32ch 69 -> 47 us, 256x256x64ch 448 -> 323 us,
 // but 64x64 and smaller lose: too few workgroups, each walking a halo that is mostly padding).  The batch size is
 // deliberately not part of the rule: the kernel serving a layer must not depend on it.
+// slabs per image the stem kernel pools the raw seg_hrnet3 skip tensor into; 0: pool_partial does it (plan without the
+// arrangement, or a crop whose rows make more slabs than the partials tensor reserves)
+static int stem_pools(const esahrnet_ctx& c, int height, int width) {
+    if (c.stemraw_partial < 0) return 0;
+    const int slabs = esa::stem_pool_slabs(c.cfg.cin, pad32(c.cfg.stem_width), height, width);
+    return slabs <= STEM_POOL_SLABS_MAX ? slabs : 0;
+}
+
 static bool cbam_fused(int Cp, int hh, int ww) {
     return esa::cbam_spatial_supported(Cp) && ((hh + 15) / 16) * ((ww + 31) / 32) >= 32 && !getenv("ESAHRNET_CBAM_UNFUSED");
 }
@@ -1468,7 +1499,8 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 const Tensor& t = h->tensors[o.out];
                 esa::StemParams p{static_cast<const float*>(x_dev), T(o.out), h->stemraw_w, h->stemraw_b,
                                   n, height, width, h->cfg.cin, t.Cp, 0, 0};
-                rc = esa::launch_stem(p, stream);
+                rc = stem_pools(*h, height, width) ? esa::launch_stem_pool(p, reinterpret_cast<float*>(T(o.out2)), stream)
+                                                   : esa::launch_stem(p, stream);
                 break;
             }
             case OP_POOL: case OP_MLP: case OP_MAPS: case OP_APPLY:
@@ -1487,6 +1519,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 switch (o.kind) {
             case OP_POOL: {
                 const Tensor& ti = h->tensors[o.in];
+                if (o.out == h->stemraw_partial && stem_pools(*h, height, width)) break;       // made by the stem kernel
                 const int HW = sp.lh[ti.level] * sp.lw[ti.level];
                 rc = esa::launch_pool_partial(T(o.in), reinterpret_cast<float*>(T(o.out)), n, HW, ti.Cp,
                                               std::min(Builder::POOL_SLABS, HW), stream);
@@ -1495,9 +1528,10 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
             case OP_MLP: {
                 const Tensor& tx = h->tensors[o.terms[0]];
                 const int HW = sp.lh[tx.level] * sp.lw[tx.level];
+                const int slabs = o.in == h->stemraw_partial ? stem_pools(*h, height, width) : 0;
                 rc = esa::launch_ca_mlp(reinterpret_cast<const float*>(T(o.in)), h->aux[o.aux[0]].dev, h->aux[o.aux[1]].dev,
                                         reinterpret_cast<float*>(T(o.out)), n, HW, o.nchan, tx.Cp, o.nchan / 16,
-                                        std::min(Builder::POOL_SLABS, HW), stream);
+                                        slabs ? slabs : std::min(Builder::POOL_SLABS, HW), stream);
                 break;
             }
             case OP_MAPS: {
@@ -1925,6 +1959,11 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                                           "resample_slice", "zero_slice", "sb_to_nchw", "head_gather"};
             snprintf(out->kernel, sizeof out->kernel, "%s", names[o.kind - OP_STEMRAW]);
             snprintf(out->label, sizeof out->label, "seg_hrnet3");
+            if (o.kind == OP_POOL && o.out == h->stemraw_partial && stem_pools(*h, height, width)) {
+                out->kernel[0] = 0;
+                snprintf(out->label, sizeof out->label, "seg_hrnet3 (inside stem_kernel(raw))");
+                break;
+            }
             if (o.job >= 0 && (o.kind == OP_POOL || o.kind == OP_MLP || o.kind == OP_MAPS || o.kind == OP_APPLY)) {
                 // merged launch of the group (run_forward): issued at the first member, for every member that launches at all
                 const JobGroup& g = h->jobs[o.job];

@@ -71,17 +71,34 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, long long total
 // STEM_PX consecutive pixels of a row — the kernel above re-reads them from LDS for every pixel (288 bytes of LDS per
 // 72 multiply-adds: LDS-bound at 1.7 TB/s of output), and each input sample now serves up to three pixels from a register.
 constexpr int STEM_PX = 8;
-__global__ __launch_bounds__(256) void stem1_kernel(StemParams p, int xgroups, long long total) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+// POOL (seg_hrnet3's raw skip tensor, whose CBAM needs the per-channel mean and maximum): grid (row pieces, n * H), and the
+// block also reduces its 8 x (256 / G) pixels per channel into slab `y * gridDim.x + blockIdx.x` of `pool` — the layout
+// pool_partial_kernel writes (cbam.hip), so that kernel's 537 MB read of the tensor just written is not needed.
+template <bool POOL>
+__global__ __launch_bounds__(256) void stem1_kernel(StemParams p, int xgroups, long long total, float* pool) {
+    __shared__ float psum[POOL ? 256 * 8 : 1], pmax[POOL ? 256 * 8 : 1];
     const int G = p.cout >> 3;
-    const int c8 = (int)(idx % G);
-    long long q = idx / G;
-    const int xg = (int)(q % xgroups);
-    q /= xgroups;
-    const int y = (int)(q % p.H);
-    const int n = (int)(q / p.H);
+    int c8, xg, y, n;
+    bool live = true;
+    if (POOL) {
+        const int u = (int)blockIdx.x * 256 + (int)threadIdx.x;
+        live = u < xgroups * G;
+        c8 = u % G; xg = min(u / G, xgroups - 1);
+        n = (int)blockIdx.y / p.H; y = (int)blockIdx.y - n * p.H;
+    } else {
+        const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (idx >= total) return;
+        c8 = (int)(idx % G);
+        long long q = idx / G;
+        xg = (int)(q % xgroups);
+        q /= xgroups;
+        y = (int)(q % p.H);
+        n = (int)(q / p.H);
+    }
     const int x0 = xg * STEM_PX;
+    float ps[8], pm[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ps[i] = 0.f; pm[i] = -INFINITY; }
     float w[72], b[8];
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
@@ -119,7 +136,11 @@ __global__ __launch_bounds__(256) void stem1_kernel(StemParams p, int xgroups, l
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = relu1(acc[i]);
         }
-        if (x >= p.W) continue;
+        if (x >= p.W || !live) continue;
+        if (POOL) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ps[i] += acc[i]; pm[i] = fmaxf(pm[i], acc[i]); }
+        }
         if (p.bf) {
             *reinterpret_cast<uint4*>(p.y + (((size_t)(n * p.H + y) * p.W + x) * p.cout) * 2 + c8 * 16) = pack8_bf16(acc);
         } else {
@@ -130,9 +151,39 @@ __global__ __launch_bounds__(256) void stem1_kernel(StemParams p, int xgroups, l
             *reinterpret_cast<uint4*>(o + 16) = lo;
         }
     }
+    if (POOL) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { psum[threadIdx.x * 8 + i] = ps[i]; pmax[threadIdx.x * 8 + i] = pm[i]; }
+        __syncthreads();
+        if ((int)threadIdx.x < p.cout) {          // channel c = tid: over the block's pixel threads (thread = xg_local * G + c8)
+            const int cg = threadIdx.x >> 3, i = threadIdx.x & 7;
+            float a = 0.f, b = -INFINITY;
+            for (int l = 0; l < 256 / G; ++l) { a += psum[(l * G + cg) * 8 + i]; b = fmaxf(b, pmax[(l * G + cg) * 8 + i]); }
+            const size_t slab = (size_t)y * gridDim.x + blockIdx.x, P = (size_t)p.H * gridDim.x;
+            float* o = pool + (((size_t)n * P + slab) * p.cout + threadIdx.x) * 2;
+            o[0] = a; o[1] = b;
+        }
+    }
 }
 
 }  // namespace
+
+// slabs launch_stem_pool writes per image (0: not available for these parameters)
+int stem_pool_slabs(int cin, int cout, int H, int W) {
+    if (cin != 1 || cout != 64 || H < 1 || W < 1) return 0;         // 256 threads = 32 pixel groups x 8 channel groups
+    const int xgroups = (W + STEM_PX - 1) / STEM_PX;
+    return H * ((xgroups * (cout >> 3) + 255) / 256);
+}
+
+// conv1 as launch_stem computes it + per-slab (sum, max) of every channel into pool[N][slabs][cout][2]
+int launch_stem_pool(const StemParams& p, float* pool, hipStream_t stream) {
+    const int slabs = stem_pool_slabs(p.cin, p.cout, p.H, p.W);
+    if (!slabs || !pool || p.bf || (long long)p.N * p.H > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const int xgroups = (p.W + STEM_PX - 1) / STEM_PX;
+    const dim3 grid((unsigned)((xgroups * (p.cout >> 3) + 255) / 256), (unsigned)(p.N * p.H));
+    hipLaunchKernelGGL(stem1_kernel<true>, grid, dim3(256), 0, stream, p, xgroups, 0LL, pool);
+    return (int)hipGetLastError();
+}
 
 int launch_stem(const StemParams& p, hipStream_t stream) {
     if ((p.cout & 31) || p.cin < 1 || p.cin > 4) return (int)hipErrorInvalidValue;
@@ -141,7 +192,7 @@ int launch_stem(const StemParams& p, hipStream_t stream) {
         const long long total1 = (long long)p.N * p.H * xgroups * (p.cout >> 3);
         const long long nblk1 = (total1 + 255) / 256;
         if (nblk1 <= 0 || nblk1 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-        hipLaunchKernelGGL(stem1_kernel, dim3((unsigned)nblk1), dim3(256), 0, stream, p, xgroups, total1);
+        hipLaunchKernelGGL(stem1_kernel<false>, dim3((unsigned)nblk1), dim3(256), 0, stream, p, xgroups, total1, nullptr);
         return (int)hipGetLastError();
     }
     const long long total = (long long)p.N * p.H * p.W * (p.cout >> 3);
