@@ -579,6 +579,18 @@ def test_hrnet3_cbam_forms_agree(env, monkeypatch):
         y2, ops2 = net1.forward_timed(x)
     assert "cbam_spatial" not in {o["kernel"] for o in ops2} and "cbam_maps" in {o["kernel"] for o in ops2}
     assert (y2 - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+    # plan-time alternatives of the same handle family: pooling of the raw stem tensor by pool_partial instead of inside
+    # the stem kernel, and the direct head convolution on 32-cout slices (no padding of head0 to 512 channels)
+    for name in ("ESAHRNET_NO_CBAM_JOBS", "ESAHRNET_CBAM_UNFUSED"):
+        monkeypatch.delenv(name, raising=False)
+    for name in ("ESAHRNET_STEM_POOL_SEPARATE", "ESAHRNET_HEAD3_COUT32"):
+        monkeypatch.setenv(name, "1")
+        net3, _ = _build(env, "seg_hrnet3", (32, 64, 128, 256), 13)
+        with torch.no_grad():
+            y3, ops3 = net3.forward_timed(x)        # (the handle, and with it the plan, is created at the first forward)
+        monkeypatch.delenv(name)
+        assert len(ops3) != len(ops) or [o["kernel"] for o in ops3] != [o["kernel"] for o in ops], name
+        assert (y3 - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item()), name
 
 
 def test_every_legal_crop_size_runs(env):
