@@ -170,19 +170,29 @@ class HighResolutionNet(nn.Module):
         if ts is None:
             ts = [t for t in self.state_dict(keep_vars=True).values()]
             self.__dict__["_wt_cache"] = ts
-            step = max(1, len(ts) // 8)
-            self.__dict__["_wt_sentinels"] = ts[::step] + ts[-1:]
         return ts
 
     def _weights_key(self):
-        """What the folded/packed weights on a device are valid for.  load_state_dict, init_weights and
-        every conversion (.cuda()/.to()/.float()) bump the epoch through the hooks below; in-place edits
-        under no_grad are noticed through the autograd version counters of nine sentinel tensors spread
-        over the state_dict (any loop over the parameters touches them) — walking all 539 counters costs
-        40 us per forward, the reference calls the net once per image (val.py:112).  After editing single
-        tensors by hand (or through `.data`, which no version counter sees) call invalidate_weights()."""
-        self._weight_tensors()
-        return (self.__dict__.get("_wt_epoch", 0), *[t._version for t in self.__dict__["_wt_sentinels"]])
+        """What the folded/packed weights on a device are valid for: "the weights are what the Parameters
+        say" (the reference's semantics).  load_state_dict, init_weights and every conversion
+        (.cuda()/.to()/.float()) bump the epoch through the hooks below; an in-place edit of ANY parameter or
+        buffer (under no_grad, by an optimizer step, ...) is seen through that tensor's autograd version
+        counter: the key holds all of them (~40 us per forward for 539 tensors, 1.5 % of a batch-32 step).
+        Only writes through `.data` / `.detach()` aliases are invisible to version counters: call
+        invalidate_weights() after those.  A caller that runs the net once per image (val.py:112) and never
+        touches the weights can drop the walk with freeze_weights()."""
+        ts = self._weight_tensors()
+        if self.__dict__.get("_wt_frozen", False):
+            return (self.__dict__.get("_wt_epoch", 0),)
+        return (self.__dict__.get("_wt_epoch", 0), *[t._version for t in ts])
+
+    def freeze_weights(self, frozen: bool = True):
+        """Opt-in fast path for per-image loops: promise that no parameter or buffer is edited in place until
+        freeze_weights(False) / invalidate_weights() / load_state_dict() / a conversion; the forward then checks
+        the epoch only (1 us instead of 40 us of host time)."""
+        self.invalidate_weights()               # whatever was edited before the promise is folded in once
+        self.__dict__["_wt_frozen"] = bool(frozen)
+        return self
 
     def invalidate_weights(self):
         """Force a re-fold on the next forward (see _weights_key)."""
