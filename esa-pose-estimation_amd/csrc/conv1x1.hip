@@ -212,7 +212,7 @@ int launch_conv1x1_n(const ConvParams& p, hipStream_t stream) {
 // weights must be packed with pack_conv_weights(k = 1): [Coutp/16][Cinp/32][hi|lo][64] fragments — the
 // 4*NCH fragments of a 32-cout chunk are contiguous, which is what the staging above relies on
 bool conv1x1_supported(const ConvParams& p) {
-    if (p.bf) {         // blocks of 64 input channels; every width of the BF plans (64 .. 768 channels)
+    if ((p.fmt == FMT_BF)) {         // blocks of 64 input channels; every width of the BF plans (64 .. 768 channels)
         const int n = p.Cinp / 64;
         return (p.Cinp % 64) == 0 && (p.Coutp % 64) == 0 && !p.res && !p.out_f32 && p.H == p.OH && p.W == p.OW &&
                (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12);
@@ -224,7 +224,7 @@ bool conv1x1_supported(const ConvParams& p) {
 
 int launch_conv1x1(const ConvParams& p, hipStream_t stream) {
     if (!conv1x1_supported(p)) return (int)hipErrorInvalidValue;
-    if (p.bf) {
+    if ((p.fmt == FMT_BF)) {
         switch (p.Cinp / 64) {
             case 1: return launch_conv1x1_n<1, true>(p, stream);
             case 2: return launch_conv1x1_n<2, true>(p, stream);
@@ -251,7 +251,7 @@ bool conv1x1_jobs_supported(const ConvParams* ps, int n) {
     if (n < 2 || n > C1_MAXJOBS) return false;
     for (int j = 0; j < n; ++j) {
         const int nch = ps[j].Cinp / 32;
-        if (ps[j].bf || ps[j].out_f32 || !conv1x1_supported(ps[j]) || (nch != 2 && nch != 4 && nch != 8)) return false;
+        if ((ps[j].fmt != FMT_SB) || ps[j].out_f32 || !conv1x1_supported(ps[j]) || (nch != 2 && nch != 4 && nch != 8)) return false;
     }
     return true;
 }

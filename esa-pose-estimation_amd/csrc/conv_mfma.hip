@@ -522,9 +522,10 @@ int launch_t(const ConvParams& p, hipStream_t stream) {
 namespace {
 // which kernel serves a convolution.  The choice must not depend on the batch size: a crop's result is
 // bit-identical in any batch (tests/test_gpu_parity.py).
-enum Choice { C_NONE, C_STREAM_S1, C_TILE_S1_8, C_TILE_S1_16, C_STREAM_S2, C_TILE_S2, C_1X1, C_TILE_1X1 };
+enum Choice { C_NONE, C_STREAM_S1, C_TILE_S1_8, C_TILE_S1_16, C_STREAM_S2, C_TILE_S2, C_1X1, C_TILE_1X1, C_X6 };
 Choice choose_conv(const ConvParams& p, int k, int stride) {
-    if (p.bf) {         // single-bf16 tensors: the stream kernel (every 3x3) and the register 1x1 kernel only
+    if (p.fmt == FMT_F32) return conv_x6_supported(p, k, stride) ? C_X6 : C_NONE;      // f32 tensors: bf16x6 arithmetic (conv_x6.hip)
+    if ((p.fmt == FMT_BF)) {         // single-bf16 tensors: the stream kernel (every 3x3) and the register 1x1 kernel only
         if (k == 3 && stride == 1) return conv_s2c32_supported(p) ? C_STREAM_S1 : C_NONE;
         if (k == 3 && stride == 2) return conv_s2c32_supported(p) ? C_STREAM_S2 : C_NONE;
         if (k == 1 && stride == 1) return conv1x1_supported(p) ? C_1X1 : C_NONE;
@@ -567,6 +568,7 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
         case C_TILE_S2: return launch_t<3, 2, 4, 2>(p, stream);
         case C_1X1: return launch_conv1x1(p, stream);
         case C_TILE_1X1: return launch_t<1, 1, 16, 2>(p, stream);
+        case C_X6: return launch_conv_x6(p, k, stride, stream);
         default: return (int)hipErrorInvalidValue;
     }
 }
@@ -576,7 +578,8 @@ int launch_conv(const ConvParams& p, int k, int stride, hipStream_t stream) {
 const char* conv_kernel_name(const ConvParams& p, int k, int stride) {
     const bool ring = ESA_CONV_RING && p.Cinp > 32;
     const bool persist = p.Cinp == 32;
-    if (p.bf) {
+    if (p.fmt == FMT_F32) return choose_conv(p, k, stride) == C_X6 ? conv_x6_kernel_name(p, k, stride) : "none";
+    if ((p.fmt == FMT_BF)) {
         switch (choose_conv(p, k, stride)) {
             case C_STREAM_S1: return "conv_s2c32_kernel<1, 8, 4, false, true>";
             case C_STREAM_S2: return "conv_s2c32_kernel<2, 4, 4, false, true>";

@@ -545,7 +545,7 @@ uint32_t magic_of(int d) { return (uint32_t)(0xffffffffull / (uint64_t)d); }
 // layer — and with it every bit of a crop's result — never depends on the batch size.
 std::atomic<long long> g_launch_limit{0x7fffffffLL};      // bytes; lowered only by tests (esahrnet_debug_set_launch_limit)
 int images_per_launch(const ConvParams& p) {
-    const int eb = p.bf ? 2 : 4;
+    const int eb = (p.fmt == FMT_BF) ? 2 : 4;
     long long per = (long long)p.H * p.W * p.Cinp * eb;
     if (p.nheads > 1) {
         for (int h = 0; h < p.nheads; ++h) per = std::max(per, (long long)p.OH * p.OW * (p.hb[h + 1] - p.hb[h]) * eb);
@@ -621,7 +621,7 @@ void set_stream_launch_limit(long long bytes) {
 // one IMAGE must be addressable with 31-bit byte offsets (buffer descriptors, OOB marker 2^31); a batch that is not
 // is cut into image ranges by the launcher (images_per_launch), so this predicate does not look at N
 bool conv_s2c32_supported(const ConvParams& p) {
-    if (p.bf) return (p.Cinp & 63) == 0 && p.Cinp >= 64 && (p.Coutp & 63) == 0 && !p.out_f32 && p.nheads <= 1 &&
+    if ((p.fmt == FMT_BF)) return (p.Cinp & 63) == 0 && p.Cinp >= 64 && (p.Coutp & 63) == 0 && !p.out_f32 && p.nheads <= 1 &&
                      (long long)p.H * p.W * p.Cinp * 2 < 0x7fffffffLL && (long long)p.OH * p.OW * p.Coutp * 2 < 0x7fffffffLL;
     return (p.Cinp & 31) == 0 && p.Cinp >= 32 && (p.Coutp & 31) == 0 && !p.out_f32 &&
            (long long)p.H * p.W * p.Cinp * 4 < 0x7fffffffLL &&
@@ -630,12 +630,12 @@ bool conv_s2c32_supported(const ConvParams& p) {
 
 int launch_conv_s2c32(const ConvParams& p, hipStream_t stream) {
     if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
-    if (p.bf) return launch_s2c32_t<2, 4, 4, false, true>(p, stream);
+    if ((p.fmt == FMT_BF)) return launch_s2c32_t<2, 4, 4, false, true>(p, stream);
     return (p.Coutp % 64 == 0) ? launch_s2c32_t<2, 4, 4>(p, stream) : launch_s2c32_t<2, 4, 2>(p, stream);
 }
 
 bool conv_s2c32_multi_supported(const ConvParams& p) {
-    if (p.bf) return false;
+    if ((p.fmt == FMT_BF)) return false;
     if (p.nheads < 2 || p.nheads > 3 || p.res || p.out_f32 || p.hb[0] != 0 || p.hb[p.nheads] != p.Coutp) return false;
     if ((p.Cinp & 31) || p.Cinp < 32 || (long long)p.H * p.W * p.Cinp * 4 >= 0x7fffffffLL) return false;
     for (int h = 0; h < p.nheads; ++h) {
@@ -663,14 +663,14 @@ int launch_conv_s2c32_multi(const ConvParams& p, hipStream_t stream) {
 // loses more to its own stalls than the longer step wins back — and the residual is folded at another point of the
 // accumulation, so results are not bit-identical to the 8-row tile.  Not used.
 bool use_th16(const ConvParams& p) {
-    if (!S2_TH16 || p.bf || p.Coutp % 64 != 0 || p.OH < 16) return false;
+    if (!S2_TH16 || (p.fmt == FMT_BF) || p.Coutp % 64 != 0 || p.OH < 16) return false;
     const long long items16 = (long long)p.N * ((p.OH + 15) / 16) * ((p.OW + 15) / 16) * (p.Coutp / 64);
     return items16 >= device_cus();
 }
 
 int launch_conv_s1w(const ConvParams& p, hipStream_t stream) {
     if (!conv_s2c32_supported(p)) return (int)hipErrorInvalidValue;
-    if (p.bf) return launch_s2c32_t<1, 8, 4, false, true>(p, stream);
+    if ((p.fmt == FMT_BF)) return launch_s2c32_t<1, 8, 4, false, true>(p, stream);
 #if S2_TH16
     if (use_th16(p)) return launch_s2c32_t<1, 16, 4>(p, stream);
 #endif
@@ -683,7 +683,7 @@ bool conv_jobs_supported(const ConvParams* ps, int n, int stride) {
     if (n < 2 || n > MAXJOBS || (stride != 1 && stride != 2)) return false;
     for (int j = 0; j < n; ++j) {
         const ConvParams& p = ps[j];
-        if (p.bf != ps[0].bf || p.nheads > 1 || p.out_f32 || p.Coutp % (p.bf ? 64 : 32) != 0 || !conv_s2c32_supported(p)) return false;
+        if (p.fmt != ps[0].fmt || p.nheads > 1 || p.out_f32 || p.Coutp % ((p.fmt == FMT_BF) ? 64 : 32) != 0 || !conv_s2c32_supported(p)) return false;
         if (images_per_launch(p) < p.N || (stride == 1 && (p.H != p.OH || p.W != p.OW || use_th16(p)))) return false;
         if (stride == 2 && (p.OH != (p.H + 1) / 2 || p.OW != (p.W + 1) / 2 || p.res)) return false;
     }
@@ -736,8 +736,8 @@ static int launch_jobs_t(const ConvParams* ps, int n, hipStream_t stream) {
 
 int launch_conv_jobs(const ConvParams* ps, int n, int stride, hipStream_t stream) {
     if (!conv_jobs_supported(ps, n, stride)) return (int)hipErrorInvalidValue;
-    if (stride == 1) return ps[0].bf ? launch_jobs_t<1, 8, true>(ps, n, stream) : launch_jobs_t<1, 8, false>(ps, n, stream);
-    return ps[0].bf ? launch_jobs_t<2, 4, true>(ps, n, stream) : launch_jobs_t<2, 4, false>(ps, n, stream);
+    if (stride == 1) return (ps[0].fmt == FMT_BF) ? launch_jobs_t<1, 8, true>(ps, n, stream) : launch_jobs_t<1, 8, false>(ps, n, stream);
+    return (ps[0].fmt == FMT_BF) ? launch_jobs_t<2, 4, true>(ps, n, stream) : launch_jobs_t<2, 4, false>(ps, n, stream);
 }
 
 }  // namespace esa

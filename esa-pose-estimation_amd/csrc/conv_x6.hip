@@ -1,0 +1,467 @@
+// conv_x6.hip — 3x3 (stride 1 / 2) and 1x1 convolution (+ folded-BN bias, optional residual, ReLU) in fp32-grade
+// arithmetic on the bf16 matrix cores: the "bf16x6" mode (esahrnet_cfg.precision 2), tensors in plain f32 NHWC ("F32").
+//
+// Replaces (reference, cuDNN fp32 via ATen): every nn.Conv2d + BatchNorm2d + ReLU (+ residual add) of
+// models/seg_hrnet.py except the stem conv1 and output_layer — BasicBlock :45-61, transitions :343-377, fuse layers
+// :176-220, last_layer :313-329 — at the precision the reference computes in (BASELINE configs[1]: fp32).
+//
+// Arithmetic.  Every f32 operand v is split EXACTLY into three bf16 terms, v = v0 + v1 + v2 (round-to-nearest-even at
+// each stage: 8 + 8 + 8 significand bits, fp32 exponent range), and a product a*b is evaluated as
+//     a0*b0 + a0*b1 + a1*b0 + a0*b2 + a1*b1 + a2*b0            (six v_mfma_f32_16x16x32_bf16, f32 accumulation)
+// — the dropped terms a1*b2 + a2*b1 + a2*b2 are below 2^-26 |a*b|.  Measured on MI355X against fp64
+// (tools/ubench/x6_numerics.hip, K = 288 .. 4320): rms error 2.4e-8 of sum|a*b| for signed and 4.6e-7 for all-positive
+// products; a sequential f32 fmaf chain (and v_mfma_f32_16x16x4_f32, which is bit-identical to it) has 2.8e-8 / 7.2e-7;
+// all nine products buy nothing over six.  Ceiling: 2.5 PFLOP/s / 6 = 417 TFLOP/s algorithmic = 2.65 x the f32 peak.
+// Weights are split on the host (pack_conv_weights_x6); activations stay f32 in HBM (4 bytes per channel, the bytes of
+// the split-bf16 format) and are split by the staging threads on their way into LDS, once per workgroup and tile — the
+// epilogue stores accumulators as they are.
+//
+// Tiling.  256 threads = 4 waves, ONE workgroup per CU (up to 512 VGPRs per lane): a wave owns one 16-cout MFMA tile x NR
+// rows x 16 columns; every B fragment (16 pixels x 32 channels of one term) read from LDS feeds 6 MFMAs per tap and up
+// to three taps; the wave's weights — 9 taps x 3 terms = 27 fragments of a 32-channel chunk — live in registers and are
+// refilled kx-third by kx-third for the next step as soon as a phase is done.  The workgroup covers 16*CT couts x
+// (4/CT)*NR rows (64 couts x 16 rows at stride 1); it walks a persistent stream of (item, chunk) steps with two tile
+// buffers in LDS and ONE barrier per step: the tile of step s+1 is loaded, split and written while step s computes.
+// A step is 864 MFMAs per wave at stride 1 (13.8 k cycles) against 3 barriers and 216 MFMAs in the split-bf16 stream
+// kernel (conv_s2c32.hip).  (A wave with TWO cout tiles — twice the MFMAs per LDS read — needs 216 weight registers and
+// spilled at 512; LDS reads are 2.6 k of a step's 13.8 k cycles as it is.)
+//
+// K order inside a 32-channel chunk.  A staging thread (pixel, sg) loads two 16-byte quads of the pixel's 128-byte
+// chunk: channels 4sg .. 4sg+3 and 16+4sg .. 16+4sg+3 — four consecutive lanes read 64 contiguous bytes per load —
+// so MFMA K index (k-group sg, element j) is channel  j < 4 ? 4sg + j : 16 + 4sg + (j - 4);  the packed weights use
+// the same permutation (x6_chan_of_k).
+#include <algorithm>
+#include <type_traits>
+
+#include "conv_cfg.h"
+#include "devstate.h"
+#include "kernels.h"
+#include "sb.h"
+
+namespace esa {
+
+__host__ __device__ constexpr int x6_chan_of_k(int sg, int j) { return j < 4 ? 4 * sg + j : 16 + 4 * sg + (j - 4); }
+
+size_t packed_weight_bytes_x6(int coutp, int cinp, int k) { return (size_t)(coutp / 16) * (cinp / 32) * k * k * 3 * 1024; }
+
+static inline uint16_t x6_host_bf16(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);       // round to nearest even (finite inputs)
+    return (uint16_t)(u >> 16);
+}
+static inline float x6_host_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+// [cout16 tile][cin32 chunk][tap][term 0..2][lane 0..63][8 x bf16], lane l holding
+// W[cout = tile*16 + (l&15)][cin = chunk*32 + x6_chan_of_k(l>>4, j)] split into three bf16 terms
+void pack_conv_weights_x6(const float* w, int cout, int cin, int k, int coutp, int cinp, void* dst) {
+    uint16_t* d = static_cast<uint16_t*>(dst);
+    const int taps = k * k, nch = cinp / 32;
+    for (int t16 = 0; t16 < coutp / 16; ++t16)
+        for (int c = 0; c < nch; ++c)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = t16 * 16 + (l & 15), ci = c * 32 + x6_chan_of_k(l >> 4, j);
+                        float v = 0.f;
+                        if (co < cout && ci < cin) v = w[((size_t)co * cin + ci) * taps + tap];
+                        const size_t base = ((((size_t)t16 * nch + c) * taps + tap) * 3) * 512;
+                        float r = v;
+                        for (int t = 0; t < 3; ++t) {
+                            const uint16_t h = x6_host_bf16(r);
+                            d[base + t * 512 + l * 8 + j] = h;
+                            r -= x6_host_f32(h);
+                        }
+                    }
+}
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+constexpr uint32_t X6_OOB = 0x80000000u;      // offset >= every descriptor's num_records (all < 2^31)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// (a, b) -> three dwords of packed bf16 (a in the low half): a = h + m + l exactly, likewise b
+__device__ __forceinline__ void x6_split_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    const f32x2 v = {a, b};
+    h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u)};
+    m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    const f32x2 s = {r[0] - __uint_as_float(m << 16), r[1] - __uint_as_float(m & 0xffff0000u)};
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(s, bf16x2));
+}
+
+template <int KS, int S, int CT, int NR>
+struct X6Cfg {
+    static constexpr int RG = 4 / CT;                       // row groups
+    static constexpr int TH = RG * NR;                      // output rows per workgroup tile
+    static constexpr int PAD = (KS - 1) / 2;
+    static constexpr int TAPS = KS * KS;
+    static constexpr int IH = (TH - 1) * S + KS;
+    static constexpr int IW = (TW - 1) * S + KS;
+    static constexpr int NPIX = IH * IW;
+    static constexpr int PLANE = ((NPIX * 16 + 128 + 255) / 256) * 256;
+    static constexpr int XBYTES = 12 * PLANE;               // one tile buffer: 4 k-groups x 3 terms
+    static constexpr int LDS = 2 * XBYTES;
+    static constexpr int XITER = (NPIX * 4 + NTHREADS - 1) / NTHREADS;
+    static constexpr int ROWS = (NR - 1) * S + KS;          // input rows a wave touches
+    // B-operand reads (ds_read_b128: lane groups pair k-groups {0,1} and {2,3}, one term per instruction) want the
+    // planes of a k-group pair congruent mod 256 B at stride 1 and one 16-byte slot apart at stride 2 (conv_cfg.h)
+    __host__ __device__ static constexpr int plane_off(int g, int t) { return (g * 3 + t) * PLANE + (S == 2 ? (g & 1) * 16 : 0); }
+    static_assert(LDS <= 160 * 1024, "tile buffers exceed the CU's LDS");
+};
+
+// tile stream geometry; m_* = floor((2^32 - 1) / d): q = umulhi(b, m) is b / d or one less
+struct X6Geo {
+    int tiles_x, tiles_y, ctiles, nitems;
+    uint32_t m_ct, m_tx, m_ty;
+};
+__device__ __forceinline__ int x6_div(int b, int d, uint32_t m) {
+    int q = (int)__umulhi((uint32_t)b, m);
+    if (b - q * d >= d) ++q;
+    return q;
+}
+
+struct X6Pos {            // one (item, chunk) step of the workgroup's stream
+    int item, c, n, oy0, ox0, ct;
+    bool ok;
+};
+
+template <int KS, int S, int CT, int NR>
+__device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, const int bid, const int G) {
+    using C = X6Cfg<KS, S, CT, NR>;
+    constexpr int TAPS = C::TAPS, ROWS = C::ROWS, XITER = C::XITER;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, px = lane & 15;
+    const int cw = wave % CT, rg = wave / CT;
+    const int nchunks = p.Cinp >> 5;
+    const int pixb = p.Cinp * 4, opix = p.Coutp * 4;
+    const uint32_t ximg = (uint32_t)p.H * p.W * pixb, yimg = (uint32_t)p.OH * p.OW * opix;     // < 2^31, host-checked
+
+    X6Pos cur;
+    cur.item = xcd_contiguous(bid, G);
+    if (cur.item >= geo.nitems) return;
+    auto decode = [&](X6Pos& q) {
+        const int q1 = x6_div(q.item, geo.ctiles, geo.m_ct);
+        q.ct = q.item - q1 * geo.ctiles;
+        const int q2 = x6_div(q1, geo.tiles_x, geo.m_tx);
+        const int tx = q1 - q2 * geo.tiles_x;
+        q.n = x6_div(q2, geo.tiles_y, geo.m_ty);
+        const int ty = q2 - q.n * geo.tiles_y;
+        q.oy0 = ty * C::TH;
+        q.ox0 = tx * TW;
+    };
+    auto advance = [&](const X6Pos& a) {
+        X6Pos q = a;
+        if (q.c + 1 < nchunks) {
+            ++q.c;
+        } else {
+            q.c = 0;
+            q.item += G;
+            q.ok = a.ok && q.item < geo.nitems;
+            if (q.ok) decode(q);
+        }
+        return q;
+    };
+
+    // ---- staging map: thread -> (k-group sg, tile pixel q0 + 64*it), fixed for the launch ----
+    const int sg = tid & 3, q0 = tid >> 2;
+    int qyx[XITER];                             // tile-local (row << 8 | column), -1 beyond the tile
+#pragma unroll
+    for (int it = 0; it < XITER; ++it) {
+        const int q = q0 + it * 64;
+        const int qy = q / C::IW, qx = q - qy * C::IW;
+        qyx[it] = q < C::NPIX ? (qy << 8 | qx) : -1;
+    }
+    // The tile of step s+1 is staged INSIDE step s in two halves (units [0, XH) and [XH, XITER)): loads at the start of a
+    // phase, split + LDS writes behind it — a unit lives in registers for one phase, not for a whole step.
+    constexpr int XH = KS == 1 ? XITER : (XITER + 1) / 2;
+    u32x4 xr[XH][2];                            // the half in flight: two quads of 4 channels per unit
+    auto load_tile = [&](const X6Pos& q, auto half_c) __attribute__((always_inline)) {
+        constexpr int i0 = decltype(half_c)::value * XH;
+        const __amdgpu_buffer_rsrc_t rx = x6_rsrc(p.x + (size_t)q.n * ximg, q.ok ? ximg : 0u);      // (no step behind: zeros, no traffic)
+        const int gy0 = q.oy0 * S - C::PAD, gx0 = q.ox0 * S - C::PAD;
+        const int so = q.c * 128;
+#pragma unroll
+        for (int it = i0; it < i0 + XH && it < XITER; ++it) {
+            const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
+            const bool inside = qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const uint32_t off = inside ? (uint32_t)((gy * p.W + gx) * pixb + sg * 16) : X6_OOB;
+            xr[it - i0][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so, 0);
+            xr[it - i0][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so + 64, 0);
+        }
+    };
+    char* const xwr = smem + q0 * 16 + sg * (3 * C::PLANE) + (S == 2 ? (sg & 1) * 16 : 0);      // plane_off(sg, 0) + pixel slot
+    auto write_tile = [&](int buf, auto half_c) __attribute__((always_inline)) {
+        constexpr int i0 = decltype(half_c)::value * XH;
+#pragma unroll
+        for (int it = i0; it < i0 + XH && it < XITER; ++it) {
+            if (q0 + it * 64 >= C::NPIX) continue;
+            u32x4 t0, t1, t2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    uint32_t a, b, c;
+                    x6_split_pair(__uint_as_float(xr[it - i0][h][2 * k]), __uint_as_float(xr[it - i0][h][2 * k + 1]), a, b, c);
+                    t0[2 * h + k] = a; t1[2 * h + k] = b; t2[2 * h + k] = c;
+                }
+            char* o = xwr + buf * C::XBYTES + it * 1024;
+            *reinterpret_cast<u32x4*>(o) = t0;
+            *reinterpret_cast<u32x4*>(o + C::PLANE) = t1;
+            *reinterpret_cast<u32x4*>(o + 2 * C::PLANE) = t2;
+        }
+    };
+
+    // ---- weights: registers wf[m][tap][term]; third kx = taps ky*KS + kx ----
+    bf16x8 wf[TAPS][3];
+    auto load_w = [&](int ct, int ch, int kx) __attribute__((always_inline)) {
+        const uint4* ws = p.w + ((size_t)((ct * CT + cw) * nchunks + ch) * TAPS) * 3 * 64 + lane;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                wf[ky * KS + kx][t] = __builtin_bit_cast(bf16x8, ws[((ky * KS + kx) * 3 + t) * 64]);
+    };
+    auto load_bias = [&](int ct) { return *reinterpret_cast<const f32x4*>(p.bias + (ct * CT + cw) * 16 + g * 4); };
+
+    // ---- prologue: tile of step 0 into buffer 0, tile of step 1 in flight, weights of step 0 ----
+    cur.c = 0;
+    cur.ok = true;
+    decode(cur);
+    constexpr auto H0 = std::integral_constant<int, 0>{};
+    constexpr auto H1 = std::integral_constant<int, 1>{};
+    load_tile(cur, H0);
+    write_tile(0, H0);
+    if constexpr (XH < XITER) {
+        load_tile(cur, H1);
+        write_tile(0, H1);
+    }
+    X6Pos nxt = advance(cur);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) load_w(cur.ct, 0, kx);
+    f32x4 bv = load_bias(cur.ct);
+
+    const char* const xrd0 = smem + ((rg * NR * S) * C::IW + px * S) * 16 + C::plane_off(0, 0) + g * (3 * C::PLANE) +
+                             (S == 2 ? (g & 1) * 16 : 0);
+    f32x4 acc[NR];
+    int buf = 0;
+    while (true) {
+        __syncthreads();        // tile of this step published; every wave is done reading the other buffer
+        const bool last_chunk = cur.c + 1 == nchunks;
+        const bool reload = nxt.ok && (nchunks > 1 || nxt.ct != cur.ct);
+        if (cur.c == 0) {
+#pragma unroll
+            for (int t = 0; t < NR; ++t) acc[t] = bv;
+        }
+        // output addressing of this wave's rows; the residual rows (last chunk) are loaded a few rows ahead of their use
+        const int co0 = (cur.ct * CT + cw) * 16 + g * 4;
+        const int rox = cur.ox0 + px, roy = cur.oy0 + rg * NR;
+        const uint32_t o0 = rox < p.OW ? (uint32_t)((roy * p.OW + rox) * opix + co0 * 4) : X6_OOB;
+        const int orow = p.OW * opix;
+        const int nrows = p.OH - roy;
+        const bool do_res = p.res != nullptr;
+        const __amdgpu_buffer_rsrc_t rr = x6_rsrc((do_res ? p.res : p.y) + (size_t)cur.n * yimg, do_res ? yimg : 0u);
+        const __amdgpu_buffer_rsrc_t ry = x6_rsrc(p.y + (size_t)cur.n * yimg, yimg);
+        const int rfl = relu_floor(p.relu);
+        constexpr int RCN = NR < 6 ? NR : 6;       // residual rows in flight (a row's load is issued RCN - 1 rows before its epilogue)
+        u32x4 rc[RCN];
+        // (unconditional: without a residual the descriptor is empty and the loads return zeros — a load behind a run-time
+        // condition makes hipcc drain vmcnt(0) at the join)
+        auto res_load = [&](int t) __attribute__((always_inline)) {
+            const uint32_t ro = t < nrows ? o0 + (uint32_t)(t * orow) : X6_OOB;
+            rc[t % RCN] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ro, 0, 0);
+        };
+        auto epilogue_row = [&](int t) __attribute__((always_inline)) {
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(relu_opt(acc[t][k] + __uint_as_float(rc[t % RCN][k]), rfl));
+            const uint32_t so = t < nrows ? o0 + (uint32_t)(t * orow) : X6_OOB;
+            // (image base in the descriptor, scalar offset the constant 0: see the store-data hazard note in
+            // conv_s2c32.hip — hipcc pads 16-byte buffer stores only when they carry no SGPR soffset)
+            __builtin_amdgcn_raw_buffer_store_b128(o, ry, (int)so, 0, 0);
+        };
+        const char* const xrd = xrd0 + buf * C::XBYTES;
+        // One kx phase.  Accumulation order (tools/ubench/x6_numerics.hip: 7x less rounding error than one long chain, better
+        // than a 16-way blocked f32 sum on the CPU): the 3 taps x 6 products of an output row and cout tile are summed in a
+        // FRESH accumulator — the fifteen low-order products first, while the sum is small, the three a0*b0 products last —
+        // and added to the item's running sum by one VALU add, one row late (the chain's result is not waited for).
+        // The B fragments of KS input rows stay in registers: every LDS read feeds the taps of up to three output rows.
+        f32x4 tq[2];
+        auto phase = [&](auto kx_c, auto epi_c) __attribute__((always_inline)) {
+            constexpr int kx = decltype(kx_c)::value;
+            constexpr bool EPI = decltype(epi_c)::value;         // last phase of the item: rows leave as they complete
+            bf16x8 xw[KS][3];
+            if (EPI) {
+#pragma unroll
+                for (int t = 0; t < RCN - 1 && t < NR; ++t) res_load(t);
+            }
+#pragma unroll
+            for (int r = 0; r <= NR; ++r) {
+                if (r < NR) {
+                    const int lo = r == 0 ? 0 : (r - 1) * S + KS, hi = r * S + KS - 1;      // input rows not yet in the window
+#pragma unroll
+                    for (int j = lo; j <= hi; ++j)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            xw[j % KS][t] = *reinterpret_cast<const bf16x8*>(xrd + (j * C::IW + kx) * 16 + t * C::PLANE);
+                    f32x4 sm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ky = 0; ky < KS; ++ky) {
+                        const int tp = ky * KS + kx, w = (r * S + ky) % KS;
+                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][2], xw[w][0], sm, 0, 0, 0);
+                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][0], xw[w][2], sm, 0, 0, 0);
+                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][1], xw[w][1], sm, 0, 0, 0);
+                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][1], xw[w][0], sm, 0, 0, 0);
+                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][0], xw[w][1], sm, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int ky = 0; ky < KS; ++ky) {
+                        const int tp = ky * KS + kx, w = (r * S + ky) % KS;
+                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][0], xw[w][0], sm, 0, 0, 0);
+                    }
+                    tq[r & 1] = sm;
+                }
+                if (r > 0) {
+                    acc[r - 1] += tq[(r - 1) & 1];
+                    if (EPI) epilogue_row(r - 1);
+                }
+                if (EPI && r + RCN - 1 < NR) res_load(r + RCN - 1);      // into the slot the epilogue above has just read
+            }
+        };
+        constexpr auto F = std::false_type{};
+        constexpr auto T = std::true_type{};
+        if constexpr (KS == 3) {
+            // (the sched_barriers keep hipcc from hoisting the next step's loads into the phase before: the registers they
+            // fill are the ones that phase is still reading — hoisted, every third and the tile would need a second set)
+            // the other buffer is free since the barrier: the tile of step s+1 goes there, half by half
+            load_tile(nxt, H0);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(std::integral_constant<int, 0>{}, F);
+            __builtin_amdgcn_sched_barrier(0);
+            write_tile(buf ^ 1, H0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (XH < XITER) load_tile(nxt, H1);
+            if (reload) load_w(nxt.ct, nxt.c, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(std::integral_constant<int, 1>{}, F);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (XH < XITER) write_tile(buf ^ 1, H1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (reload) load_w(nxt.ct, nxt.c, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (last_chunk) phase(std::integral_constant<int, 2>{}, T);
+            else phase(std::integral_constant<int, 2>{}, F);
+            __builtin_amdgcn_sched_barrier(0);
+            if (reload) load_w(nxt.ct, nxt.c, 2);
+        } else {
+            load_tile(nxt, H0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (last_chunk) phase(std::integral_constant<int, 0>{}, T);
+            else phase(std::integral_constant<int, 0>{}, F);
+            __builtin_amdgcn_sched_barrier(0);
+            write_tile(buf ^ 1, H0);
+            if (reload) load_w(nxt.ct, nxt.c, 0);
+        }
+        if (last_chunk) {
+            if (nxt.ok && nxt.ct != cur.ct) bv = load_bias(nxt.ct);
+        }
+        if (!nxt.ok) break;
+        cur = nxt;
+        nxt = advance(cur);
+        buf ^= 1;
+    }
+}
+
+template <int KS, int S, int CT, int NR>
+__global__ __launch_bounds__(NTHREADS, 1) void conv_x6_kernel(ConvParams p, X6Geo geo) {
+    x6_body<KS, S, CT, NR>(p, geo, (int)blockIdx.x, (int)gridDim.x);
+}
+
+uint32_t x6_magic(int d) { return (uint32_t)(0xffffffffull / (uint64_t)d); }
+
+template <int KS, int S, int CT, int NR>
+int launch_x6_t(const ConvParams& p, hipStream_t stream) {
+    using C = X6Cfg<KS, S, CT, NR>;
+    X6Geo geo;
+    geo.tiles_x = (p.OW + TW - 1) / TW;
+    geo.tiles_y = (p.OH + C::TH - 1) / C::TH;
+    geo.ctiles = p.Coutp / (16 * CT);
+    const long long nitems = (long long)p.N * geo.tiles_y * geo.tiles_x * geo.ctiles;
+    if (nitems <= 0 || nitems > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    geo.nitems = (int)nitems;
+    geo.m_ct = x6_magic(geo.ctiles);
+    geo.m_tx = x6_magic(geo.tiles_x);
+    geo.m_ty = x6_magic(geo.tiles_y);
+    const int cus = device_cus();
+    int grid = (int)(nitems < cus ? nitems : cus);
+    if (grid > geo.ctiles) grid -= grid % geo.ctiles;   // grid stride keeps the cout slice of a workgroup constant
+    auto kern = conv_x6_kernel<KS, S, CT, NR>;
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), C::LDS)) return e_;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), C::LDS, stream, p, geo);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// one IMAGE must be addressable with 31-bit byte offsets (per-image buffer descriptors, OOB marker 2^31); the batch
+// size is unlimited (the image base is a 64-bit pointer)
+bool conv_x6_supported(const ConvParams& p, int k, int stride) {
+    if (p.fmt != FMT_F32 || p.out_f32 || p.nheads > 1) return false;
+    if (!((k == 3 && (stride == 1 || stride == 2)) || (k == 1 && stride == 1))) return false;
+    if ((p.Cinp & 31) || p.Cinp < 32 || (p.Coutp & 31) || p.Coutp < 32) return false;
+    if (stride == 1 && (p.OH != p.H || p.OW != p.W)) return false;
+    if (stride == 2 && (p.OH != (p.H + 1) / 2 || p.OW != (p.W + 1) / 2)) return false;
+    return (long long)p.H * p.W * p.Cinp * 4 < 0x7fffffffLL && (long long)p.OH * p.OW * p.Coutp * 4 < 0x7fffffffLL;
+}
+
+// The tiling depends on the layer's shape only, never on the batch size: a crop's result is bit-identical in any batch.
+//   couts % 64 == 0: 64 couts x 16 rows per workgroup (wave = cout tile x 16 rows); x 8 rows where an image is at most 16
+//                    rows high (the 256-channel 16x16 branch: 2 tiles per image instead of 1, the chip has 256 CUs)
+//   else           : 32 couts x 16 rows                (wave = cout tile x 8 rows)
+// stride 2: 4 output rows per workgroup in every case (the input tile is 9 x 33 pixels).
+static int x6_variant(const ConvParams& p, int k, int stride) {
+    const int ct = p.Coutp % 64 == 0 ? 4 : 2;
+    if (stride == 2) return ct == 4 ? 0 : 1;
+    if (ct == 4) return p.OH <= 16 ? 2 : 3;
+    return 4;
+}
+
+int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream) {
+    if (!conv_x6_supported(p, k, stride)) return (int)hipErrorInvalidValue;
+    const int v = x6_variant(p, k, stride);
+    if (k == 3) {
+        switch (v) {
+            case 0: return launch_x6_t<3, 2, 4, 4>(p, stream);
+            case 1: return launch_x6_t<3, 2, 2, 2>(p, stream);
+            case 2: return launch_x6_t<3, 1, 4, 8>(p, stream);
+            case 3: return launch_x6_t<3, 1, 4, 16>(p, stream);
+            default: return launch_x6_t<3, 1, 2, 8>(p, stream);
+        }
+    }
+    switch (v) {
+        case 2: return launch_x6_t<1, 1, 4, 8>(p, stream);
+        case 3: return launch_x6_t<1, 1, 4, 16>(p, stream);
+        default: return launch_x6_t<1, 1, 2, 8>(p, stream);
+    }
+}
+
+const char* conv_x6_kernel_name(const ConvParams& p, int k, int stride) {
+    static const char* n3[] = {"conv_x6_kernel<3, 2, 4, 4>", "conv_x6_kernel<3, 2, 2, 2>", "conv_x6_kernel<3, 1, 4, 8>",
+                               "conv_x6_kernel<3, 1, 4, 16>", "conv_x6_kernel<3, 1, 2, 8>"};
+    static const char* n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 8>", "conv_x6_kernel<1, 1, 4, 16>", "conv_x6_kernel<1, 1, 2, 8>"};
+    const int v = x6_variant(p, k, stride);
+    return k == 3 ? n3[v] : n1[v];
+}
+
+}  // namespace esa

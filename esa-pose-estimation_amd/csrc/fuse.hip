@@ -59,17 +59,21 @@ struct FuseScales {
 // interpolation are wave-uniform, all per-lane index math is 32-bit.  NS same-resolution terms come
 // first, then NU lower-resolution terms (the host orders them); both counts are compile-time.
 // one 8-channel group of a pixel -> 8 floats (SB: hi + lo chunks, 32 bytes; BF: one 16-byte chunk)
-template <bool BF>
+template <int FMT>
 __device__ __forceinline__ void load8(const char* pix, int c8, float v[8]) {
-    if (BF) {
+    if (FMT == FMT_BF) {
         unpack8_bf16(*reinterpret_cast<const uint4*>(pix + c8 * 16), v);
+    } else if (FMT == FMT_F32) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pix + c8 * 32), b = *reinterpret_cast<const f32x4*>(pix + c8 * 32 + 16);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     } else {
         join8(*reinterpret_cast<const uint4*>(pix + c8 * 32), *reinterpret_cast<const uint4*>(pix + c8 * 32 + 16), v);
     }
 }
 
-template <int NS, int NU, bool BF = false>
+template <int NS, int NU, int FMT = FMT_SB>
 __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) {
+    constexpr bool BF = FMT == FMT_BF;
     const int G = p.Cp >> 3;
     const unsigned u = blockIdx.x * 256u + threadIdx.x;
     if (u >= (unsigned)(p.W * G)) return;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) 
 
     float acc[8];
     if (NS > 0) {
-        load8<BF>(p.x[0] + ((size_t)row * p.W + x) * (size_t)pixb, c8, acc);
+        load8<FMT>(p.x[0] + ((size_t)row * p.W + x) * (size_t)pixb, c8, acc);
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) 
 #pragma unroll
     for (int t = 1; t < NS; ++t) {
         float v[8];
-        load8<BF>(p.x[t] + ((size_t)row * p.W + x) * (size_t)pixb, c8, v);
+        load8<FMT>(p.x[t] + ((size_t)row * p.W + x) * (size_t)pixb, c8, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += v[i];
     }
@@ -102,10 +106,10 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) 
         const char* r1 = p.x[t] + ((size_t)n * h + ly.i1) * w * (size_t)pixb;
         const int o0 = lx.i0 * pixb, o1 = lx.i1 * pixb;
         float v00[8], v01[8], v10[8], v11[8];
-        load8<BF>(r0 + o0, c8, v00);
-        load8<BF>(r0 + o1, c8, v01);
-        load8<BF>(r1 + o0, c8, v10);
-        load8<BF>(r1 + o1, c8, v11);
+        load8<FMT>(r0 + o0, c8, v00);
+        load8<FMT>(r0 + o1, c8, v01);
+        load8<FMT>(r1 + o0, c8, v10);
+        load8<FMT>(r1 + o1, c8, v11);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             acc[i] += ly.l0 * (lx.l0 * v00[i] + lx.l1 * v01[i]) + ly.l1 * (lx.l0 * v10[i] + lx.l1 * v11[i]);
@@ -116,6 +120,12 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) 
     }
     if (BF) {
         *reinterpret_cast<uint4*>(p.y + ((size_t)row * p.W + x) * (size_t)pixb + c8 * 16) = pack8_bf16(acc);
+        return;
+    }
+    if (FMT == FMT_F32) {
+        char* o = p.y + ((size_t)row * p.W + x) * (size_t)pixb + c8 * 32;
+        *reinterpret_cast<f32x4*>(o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(o + 16) = f32x4{acc[4], acc[5], acc[6], acc[7]};
         return;
     }
     uint4 hi, lo;
@@ -131,8 +141,9 @@ int launch_fuse_t(const FuseParams& p, const FuseScales& fs, hipStream_t stream)
     const long long rows = (long long)p.N * p.H;
     if (per_row <= 0 || rows <= 0 || rows > 0x7fffffffLL || per_row > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)rows);
-    if (p.bf) hipLaunchKernelGGL((fuse_kernel<NS, NU, true>), grid, dim3(256), 0, stream, p, fs);
-    else hipLaunchKernelGGL((fuse_kernel<NS, NU, false>), grid, dim3(256), 0, stream, p, fs);
+    if (p.fmt == FMT_BF) hipLaunchKernelGGL((fuse_kernel<NS, NU, FMT_BF>), grid, dim3(256), 0, stream, p, fs);
+    else if (p.fmt == FMT_F32) hipLaunchKernelGGL((fuse_kernel<NS, NU, FMT_F32>), grid, dim3(256), 0, stream, p, fs);
+    else hipLaunchKernelGGL((fuse_kernel<NS, NU, FMT_SB>), grid, dim3(256), 0, stream, p, fs);
     return (int)hipGetLastError();
 }
 

@@ -59,11 +59,15 @@ __global__ __launch_bounds__(256) void final_kernel(FinalParams p, int tiles_x, 
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
             const LerpT ly = lerp_ac_true(gy, p.h, p.H), lx = lerp_ac_true(gx, p.wd, p.W);
             const size_t r0 = ((size_t)n * p.h + ly.i0) * p.wd, r1 = ((size_t)n * p.h + ly.i1) * p.wd;
-            const size_t ps = (size_t)p.Cp * (p.bf ? 2 : 4);
+            const size_t ps = (size_t)p.Cp * (p.fmt == FMT_BF ? 2 : 4);
             float v00[8], v01[8], v10[8], v11[8];
             auto ld = [&](size_t pix, float v_[8]) {
-                if (p.bf) {
+                if (p.fmt == FMT_BF) {
                     unpack8_bf16(*reinterpret_cast<const uint4*>(p.h3 + pix * ps + c8 * 16), v_);
+                } else if (p.fmt == FMT_F32) {
+                    const float* a = reinterpret_cast<const float*>(p.h3 + pix * ps) + c8 * 8;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
+                    v_[0] = a0[0]; v_[1] = a0[1]; v_[2] = a0[2]; v_[3] = a0[3]; v_[4] = a1[0]; v_[5] = a1[1]; v_[6] = a1[2]; v_[7] = a1[3];
                 } else {
                     const char* a = p.h3 + pix * ps + c8 * 32;
                     join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v_);
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void final_mfma_kernel(FinalParams p, const
         const int q = u / NKG;
         const int sy = q / scols, sx = q - sy * scols;
         float v[8];
-        if (p.bf) {         // single-bf16 tensor (precision = 1): 2 bytes per channel
+        if (p.fmt == FMT_BF) {         // single-bf16 tensor (precision = 1): 2 bytes per channel
             const char* a = p.h3 + (((size_t)n * p.h + sy0 + sy) * p.wd + sx0 + sx) * ((size_t)p.Cp * 2) + kg * 16;
             unpack8_bf16(*reinterpret_cast<const uint4*>(a), v);
         } else {

@@ -5,6 +5,9 @@
 
 namespace esa {
 
+// tensor formats of the internal activations (sb.h): split-bf16 NHWC, single bf16 NHWC, plain f32 NHWC
+enum { FMT_SB = 0, FMT_BF = 1, FMT_F32 = 2 };
+
 // thread-local error text behind esahrnet_last_error() (plan.hip); returns 1 so that `return set_error(...)` reads well
 int set_error(const char* fmt, ...);
 
@@ -19,8 +22,9 @@ struct ConvParams {
     int Cinp, Coutp;    // multiples of 32
     int relu;
     int out_f32;        // 0: y is SB; 1: y is plain f32 NHWC [N][OH][OW][Coutp] (head terms t_b)
-    int bf;             // 1: x, y, res are BF tensors (single bf16, sb.h), Cinp / Coutp multiples of 64, weights packed
-                        //    by pack_conv_weights_bf; served by the stream kernel (3x3) and conv1x1 only
+    int fmt;            // FMT_SB; FMT_BF: x, y, res are BF tensors (single bf16, sb.h), Cinp / Coutp multiples of 64, weights
+                        //    packed by pack_conv_weights_bf, served by the stream kernel (3x3) and conv1x1 only; FMT_F32: plain
+                        //    f32 NHWC tensors, weights packed by pack_conv_weights_x6, served by conv_x6.hip (bf16x6 arithmetic)
     // multi-head form (stream kernel, stride 2 only): several convolutions of the SAME input evaluated in one launch —
     // w / bias are the members' packed weights / biases concatenated along cout, Coutp their total, and head h
     // (couts hb[h] .. hb[h+1]-1 of the concatenation, multiples of 32) goes to its own SB tensor yh[h] of
@@ -63,6 +67,15 @@ void pack_conv_weights(const float* w, int cout, int cin, int k, int coutp, int 
 size_t packed_weight_bytes_bf(int coutp, int cinp, int k);
 void pack_conv_weights_bf(const float* w, int cout, int cin, int k, int coutp, int cinp, void* dst);
 
+// bf16x6 mode (conv_x6.hip): [cout16 tile][cin32 chunk][tap][term 0..2][lane][8 x bf16], every weight split exactly into
+// three bf16 terms, K order inside a chunk as the staging threads load it (x6_chan_of_k)
+size_t packed_weight_bytes_x6(int coutp, int cinp, int k);
+void pack_conv_weights_x6(const float* w, int cout, int cin, int k, int coutp, int cinp, void* dst);
+// 3x3 stride 1 / 2 and 1x1 on FMT_F32 tensors in bf16x6 arithmetic
+bool conv_x6_supported(const ConvParams& p, int k, int stride);
+int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream);
+const char* conv_x6_kernel_name(const ConvParams& p, int k, int stride);
+
 // ---- stem conv1: f32 NCHW -> SB, 3x3 s1, cin in {1..4}, cout = multiple of 32 (stem.hip) ---
 struct StemParams {
     const float* x;     // f32 [N][cin][H][W]
@@ -71,7 +84,7 @@ struct StemParams {
     const float* bias;  // f32 [cout]
     int N, H, W, cin, cout;
     int relu;           // 0: raw conv output (seg_hrnet3 keeps the pre-BN conv1 tensor for its skip)
-    int bf;             // 1: y is a BF tensor (cout = padded channel count, multiple of 64)
+    int fmt;            // format of y (FMT_BF: cout = padded channel count, multiple of 64)
 };
 int launch_stem(const StemParams& p, hipStream_t stream);
 // the same convolution + the per-channel (sum, max) of the output over slabs of pixels, in pool_partial's layout
@@ -111,7 +124,7 @@ struct FuseParams {
     char* y;
     int N, H, W, Cp;
     int relu;
-    int bf;             // 1: all tensors are BF
+    int fmt;            // format of all tensors
 };
 int launch_fuse(const FuseParams& p, hipStream_t stream);
 
@@ -125,7 +138,7 @@ struct FinalParams {
     const uint4* wpk;   // MFMA path: split-bf16 fragments (pack_final_mfma), or nullptr -> VALU kernel
     int N, H, W, h, wd; // h,wd = resolution of h3
     int K, cin, Cp;
-    int bf;             // 1: h3 is a BF tensor (VALU kernel only)
+    int fmt;            // format of h3 (FMT_F32: VALU kernel only)
     float2* part;       // optional (MFMA kernel only): [N*K][final_part_tiles] (value, index bits) of every tile's first maximum
 };
 int launch_final(const FinalParams& p, hipStream_t stream);
@@ -265,5 +278,11 @@ int launch_sb_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* 
 // the same for BF tensors (single bf16 NHWC, sb.h)
 int launch_nchw_to_bf(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s);
 int launch_bf_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s);
+// and for F32 tensors (plain f32 NHWC)
+int launch_nchw_to_f32(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s);
+int launch_f32_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s);
+// by format code
+int launch_nchw_to_fmt(int fmt, const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s);
+int launch_fmt_to_nchw(int fmt, const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s);
 
 }  // namespace esa

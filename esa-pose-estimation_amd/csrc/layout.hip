@@ -74,7 +74,66 @@ __global__ __launch_bounds__(256) void sb_to_nchw_groups_kernel(const char* x, i
         if (g * 8 + j < C) o[(size_t)j * hw] = v[j];
 }
 
+// plain f32 NHWC <-> f32 NCHW: thread = (pixel, 8-channel group), group fastest (a pixel's channels are contiguous)
+__global__ __launch_bounds__(256) void nchw_to_f32_kernel(const float* x, int C, long long hw, float* y, int Cp, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int G = Cp >> 3;
+    const int c8 = (int)(idx % G);
+    const long long pix = idx / G;
+    const long long n = pix / hw, s = pix - n * hw;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c8 * 8 + i;
+        v[i] = c < C ? x[((size_t)n * C + c) * hw + s] : 0.f;
+    }
+    float* o = y + (size_t)pix * Cp + c8 * 8;
+    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+__global__ __launch_bounds__(256) void f32_to_nchw_kernel(const float* x, int C, long long hw, int Cp, float* y, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int G = (C + 7) >> 3;
+    const int g = (int)(idx % G);
+    const long long pix = idx / G;
+    const long long n = pix / hw, sp = pix - n * hw;
+    const float* a = x + (size_t)pix * Cp + g * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
+    const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    float* o = y + ((size_t)n * C + (size_t)g * 8) * (size_t)hw + sp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (g * 8 + j < C) o[(size_t)j * hw] = v[j];
+}
+
 }  // namespace
+
+int launch_nchw_to_f32(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s) {
+    const long long total = (long long)N * H * W * (Cp >> 3);
+    const long long nblk = (total + 255) / 256;
+    if (nblk <= 0 || nblk > 0x7fffffffLL || (Cp & 7) || C > Cp) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(nchw_to_f32_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, C, (long long)H * W, reinterpret_cast<float*>(y), Cp, total);
+    return (int)hipGetLastError();
+}
+
+int launch_f32_to_nchw(const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s) {
+    const long long total = (long long)N * H * W * ((C + 7) >> 3);
+    const long long nblk = (total + 255) / 256;
+    if (nblk <= 0 || nblk > 0x7fffffffLL || C > Cp || (Cp & 7)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(f32_to_nchw_kernel, dim3((unsigned)nblk), dim3(256), 0, s, reinterpret_cast<const float*>(x), C, (long long)H * W, Cp, y, total);
+    return (int)hipGetLastError();
+}
+
+int launch_nchw_to_fmt(int fmt, const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s) {
+    return fmt == FMT_BF ? launch_nchw_to_bf(x, N, C, H, W, y, Cp, s) : fmt == FMT_F32 ? launch_nchw_to_f32(x, N, C, H, W, y, Cp, s)
+                                                                                          : launch_nchw_to_sb(x, N, C, H, W, y, Cp, s);
+}
+int launch_fmt_to_nchw(int fmt, const char* x, int N, int C, int H, int W, int Cp, float* y, hipStream_t s) {
+    return fmt == FMT_BF ? launch_bf_to_nchw(x, N, C, H, W, Cp, y, s) : fmt == FMT_F32 ? launch_f32_to_nchw(x, N, C, H, W, Cp, y, s)
+                                                                                          : launch_sb_to_nchw(x, N, C, H, W, Cp, y, s);
+}
 
 int launch_nchw_to_sb(const float* x, int N, int C, int H, int W, char* y, int Cp, hipStream_t s) {
     const long long total = (long long)N * H * W * (Cp >> 3);

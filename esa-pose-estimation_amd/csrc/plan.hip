@@ -180,8 +180,14 @@ struct esahrnet_ctx {
     bool committed = false;
     bool keep = false;
     bool bf = false;            // cfg.precision == 1: tensors are single bf16 (sb.h "BF"), channels padded to 64
+    int fmt = esa::FMT_SB;      // tensor format of the plan: FMT_SB (precision 0), FMT_BF (1), FMT_F32 (2: bf16x6 arithmetic)
+    bool x6() const { return fmt == esa::FMT_F32; }
     int padc(int ch) const { return bf ? pad64(ch) : pad32(ch); }
     int eb() const { return bf ? 2 : 4; }       // bytes per stored channel
+    size_t wbytes(int coutp, int cinp, int k) const {
+        return bf ? esa::packed_weight_bytes_bf(coutp, cinp, k) : x6() ? esa::packed_weight_bytes_x6(coutp, cinp, k)
+                                                                       : esa::packed_weight_bytes(coutp, cinp, k);
+    }
     bool fuse_big = true;       // fused stem + fused head (ESAHRNET_UNFUSED=1 selects the op-by-op plan)
     bool head2_enabled = true;  // ESAHRNET_HEAD_V1=1 keeps the first-generation fused head for every shape
     int head2_op = -1;          // index of the OP_HEAD2 op, -1 if the plan has none
@@ -363,7 +369,7 @@ struct Builder {
 // Post-pass over the op list: find the stride-2 3x3 convolutions that share their input and make each such group
 // consecutive (moving a member EARLIER is always legal: its only input is defined before the group's first member).
 void group_multihead(esahrnet_ctx& c) {
-    if (getenv("ESAHRNET_NO_MULTIHEAD") || c.bf) return;
+    if (getenv("ESAHRNET_NO_MULTIHEAD") || c.fmt != esa::FMT_SB) return;
     auto eligible = [&](const Op& o) {
         if (o.kind != OP_CONV || o.res >= 0 || o.alt != 0 || o.multi >= 0) return false;
         const DevConv& d = c.dconvs[o.dconv];
@@ -422,7 +428,7 @@ void group_multihead(esahrnet_ctx& c) {
 // branch by branch; here the convolutions of a module are put in depth-major order (stable, so every branch keeps its own
 // order) and the same-depth ones of up to three branches become a JobGroup.
 void group_jobs(esahrnet_ctx& c) {
-    if (getenv("ESAHRNET_NO_JOBS")) return;
+    if (getenv("ESAHRNET_NO_JOBS") || c.x6()) return;
     std::vector<Op> ops = c.ops;
     auto eligible = [&](const Op& o) {
         // the CBAM launches of a depth (seg_hrnet3): same kind on every branch, one launch (cbam.hip: cbam_jobs_kernel)
@@ -968,7 +974,7 @@ esa::ConvParams conv_params_of(const esahrnet_ctx& c, const Op& o, int n, const 
     p.res = o.res >= 0 ? (ws ? ws + c.tensors[o.res].off : dummy) : nullptr;
     p.w = static_cast<const uint4*>(d.w); p.bias = d.bias;
     p.N = n; p.H = lh[ti.level]; p.W = lw[ti.level]; p.OH = lh[to.level]; p.OW = lw[to.level];
-    p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu; p.out_f32 = d.out_f32; p.bf = c.bf ? 1 : 0;
+    p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu; p.out_f32 = d.out_f32; p.fmt = c.fmt;
     return p;
 }
 
@@ -1128,8 +1134,9 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     if (cfg->num_keypoints < 1 || esa::final_kt(cfg->num_keypoints) < 0) return fail("num_keypoints=%d unsupported (1..32)", cfg->num_keypoints);
     if (cfg->stem_width < 1 || cfg->blocks[0][0] < 1) return fail("bad stem_width/blocks");
     if (cfg->variant != 0 && cfg->variant != 1) return fail("variant=%d unsupported (0: seg_hrnet/2, 1: seg_hrnet3)", cfg->variant);
-    if (cfg->precision != 0 && cfg->precision != 1) return fail("precision=%d unsupported (0: split-bf16, 1: bf16)", cfg->precision);
-    if (cfg->precision == 1 && cfg->variant != 0) return fail("precision 1 (bf16) is built for variant 0 only");
+    if (cfg->precision < 0 || cfg->precision > 2)
+        return fail("precision=%d unsupported (0: split-bf16 'bf16x3', 1: bf16, 2: fp32-grade 'bf16x6')", cfg->precision);
+    if (cfg->precision != 0 && cfg->variant != 0) return fail("precision %d is built for variant 0 only", cfg->precision);
     if (cfg->variant == 1) {
         if (cfg->stem_width % 16) return fail("variant 1: stem_width must be a multiple of 16 (ChannelAttention ratio)");
         for (int b = 0; b < ESAHRNET_MAX_BRANCHES; ++b)
@@ -1146,6 +1153,11 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     if (const char* e = getenv("ESAHRNET_UNFUSED")) c->fuse_big = !(e[0] && e[0] != '0');
     if (cfg->precision == 1) {      // bf16 mode: op-by-op plan on the stream / 1x1 / fuse kernels (the fused stem, block
         c->bf = true;               // and head kernels are built for the split format only)
+        c->fuse_big = false;
+        c->fmt = esa::FMT_BF;
+    }
+    if (cfg->precision == 2) {      // fp32-grade mode: f32 NHWC tensors, bf16x6 arithmetic (conv_x6.hip); op-by-op plan
+        c->fmt = esa::FMT_F32;
         c->fuse_big = false;
     }
     if (const char* e = getenv("ESAHRNET_STREAMS")) c->nlanes = atoi(e) > 1 ? 4 : 1;
@@ -1266,6 +1278,9 @@ int esahrnet_commit(esahrnet_handle h) {
         if (h->bf) {
             packed.assign(esa::packed_weight_bytes_bf(d.coutp, d.cinp, s.k), 0);
             esa::pack_conv_weights_bf(w.data(), s.cout, cin, s.k, d.coutp, d.cinp, packed.data());
+        } else if (h->x6()) {
+            packed.assign(esa::packed_weight_bytes_x6(d.coutp, d.cinp, s.k), 0);
+            esa::pack_conv_weights_x6(w.data(), s.cout, cin, s.k, d.coutp, d.cinp, packed.data());
         } else {
             packed.assign(esa::packed_weight_bytes(d.coutp, d.cinp, s.k), 0);
             esa::pack_conv_weights(w.data(), s.cout, cin, s.k, d.coutp, d.cinp, packed.data());
@@ -1308,7 +1323,7 @@ int esahrnet_commit(esahrnet_handle h) {
         const ConvSpec& s = h->specs[h->spec_final];
         const int kt = esa::final_kt(s.cout);
         std::vector<float> w((size_t)s.cin * 9 * kt, 0.f), b(std::max(kt, 32), 0.f);
-        if (esa::final_mfma_supported(s.cout, s.cin - s.cout) && !getenv("ESAHRNET_FINAL_VALU")) {
+        if (esa::final_mfma_supported(s.cout, s.cin - s.cout) && !getenv("ESAHRNET_FINAL_VALU") && !h->x6()) {
             packed.assign(esa::final_mfma_bytes(s.cout, s.cin - s.cout), 0);
             esa::pack_final_mfma(s.w.data(), s.cout, s.cin - s.cout, packed.data());
             if (upload(packed, &h->final_wpk)) return 1;
@@ -1491,7 +1506,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
             case OP_STEM: {
                 const Tensor& t = h->tensors[o.out];
                 esa::StemParams p{static_cast<const float*>(x_dev), T(o.out), h->stem_w, h->stem_b,
-                                  n, height, width, h->cfg.cin, t.Cp, 1, h->bf ? 1 : 0};
+                                  n, height, width, h->cfg.cin, t.Cp, 1, h->fmt};
                 rc = esa::launch_stem(p, stream);
                 break;
             }
@@ -1728,7 +1743,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                     p.x[i] = T(o.terms[i]); p.h[i] = sp.lh[ti.level]; p.w[i] = sp.lw[ti.level];
                 }
                 p.y = T(o.out); p.N = n; p.H = sp.lh[to.level]; p.W = sp.lw[to.level]; p.Cp = to.Cp;
-                p.relu = o.relu; p.bf = h->bf ? 1 : 0;
+                p.relu = o.relu; p.fmt = h->fmt;
                 rc = esa::launch_fuse(p, stream);
                 break;
             }
@@ -1738,7 +1753,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 p.h3 = T(o.in); p.x0 = static_cast<const float*>(x_dev); p.out = static_cast<float*>(heat_dev);
                 p.w = h->final_w; p.bias = h->final_b; p.wpk = static_cast<const uint4*>(h->final_wpk);
                 p.N = n; p.H = height; p.W = width; p.h = sp.lh[ti.level]; p.wd = sp.lw[ti.level];
-                p.K = h->cfg.num_keypoints; p.cin = h->cfg.cin; p.Cp = ti.Cp; p.bf = h->bf ? 1 : 0;
+                p.K = h->cfg.num_keypoints; p.cin = h->cfg.cin; p.Cp = ti.Cp; p.fmt = h->fmt;
                 p.part = static_cast<float2*>(part_dev);
                 rc = esa::launch_final(p, stream);
                 break;
@@ -1870,7 +1885,7 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                     lab += (k ? " + " : "") + sk.name;
                     out->flops += 2.0 * n * lh[tk.level] * lw[tk.level] * sk.cout * sk.cin * (double)(sk.k * sk.k);
                     out->bytes += tbytes(ok.in) + tbytes(ok.out) + (ok.res >= 0 ? tbytes(ok.res) : 0.0) +
-                                  (double)(h->bf ? esa::packed_weight_bytes_bf(dk.coutp, dk.cinp, sk.k) : esa::packed_weight_bytes(dk.coutp, dk.cinp, sk.k));
+                                  (double)h->wbytes(dk.coutp, dk.cinp, sk.k);
                 }
                 snprintf(out->label, sizeof out->label, "%s", lab.c_str());
                 break;
@@ -1879,7 +1894,7 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                 const Tensor& ti = h->tensors[o.in];
                 esa::ConvParams q{};
                 q.N = n; q.H = lh[ti.level]; q.W = lw[ti.level]; q.OH = lh[to.level]; q.OW = lw[to.level];
-                q.Cinp = d.cinp; q.Coutp = d.coutp; q.out_f32 = d.out_f32; q.bf = h->bf ? 1 : 0;
+                q.Cinp = d.cinp; q.Coutp = d.coutp; q.out_f32 = d.out_f32; q.fmt = h->fmt;
                 q.res = o.res >= 0 ? reinterpret_cast<const char*>(h) : nullptr;     // only tested against nullptr
                 snprintf(out->kernel, sizeof out->kernel, "%s", esa::conv_kernel_name(q, s.k, s.stride));
             }
@@ -1887,7 +1902,7 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             else snprintf(out->label, sizeof out->label, "%s", s.name.c_str());
             out->flops = 2.0 * n * lh[to.level] * lw[to.level] * s.cout * (d.c1 - d.c0) * s.k * s.k;
             out->bytes = tbytes(o.in) + tbytes(o.out) + (o.res >= 0 ? tbytes(o.res) : 0.0) +
-                         (double)(h->bf ? esa::packed_weight_bytes_bf(d.coutp, d.cinp, s.k) : esa::packed_weight_bytes(d.coutp, d.cinp, s.k));
+                         (double)h->wbytes(d.coutp, d.cinp, s.k);
             break;
         }
         case OP_BLOCK: {
@@ -2115,7 +2130,7 @@ int esahrnet_tap_read(esahrnet_handle h, const char* name, int n, int height, in
     if (plan_shape(*h, n, height, width)) return 1;
     if (t->alt != 0 && t->alt != (h->sp.head2 ? 2 : 1))
         return fail("tap_read: '%s' belongs to the head alternative that does not run at this shape", name);
-    const int rc = (h->bf ? esa::launch_bf_to_nchw : esa::launch_sb_to_nchw)(
+    const int rc = esa::launch_fmt_to_nchw(h->fmt,
         static_cast<const char*>(ws_dev) + t->off, n, t->C, h->sp.lh[t->level], h->sp.lw[t->level], t->Cp,
         static_cast<float*>(out_dev), static_cast<hipStream_t>(stream));
     if (rc) return fail("tap_read: %s", hipGetErrorString((hipError_t)rc));
@@ -2133,15 +2148,18 @@ int esahrnet_op_conv_ex(const void* x_dev, int n, int cin, int height, int width
                         const float* b, int cout, int k, int stride, int relu, const void* res_dev,
                         void* y_dev, int precision, esahrnet_stream stream_) {
     if (!x_dev || !w || !b || !y_dev) return fail("op_conv: null argument");
-    if (precision != 0 && precision != 1) return fail("op_conv: precision %d", precision);
-    const bool bf = precision == 1;
+    if (precision < 0 || precision > 2) return fail("op_conv: precision %d", precision);
+    const bool bf = precision == 1, x6 = precision == 2;
+    const int fmt = bf ? esa::FMT_BF : x6 ? esa::FMT_F32 : esa::FMT_SB;
     const int eb = bf ? 2 : 4;
     if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return fail("op_conv: k=%d stride=%d unsupported", k, stride);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int cinp = bf ? pad64(cin) : pad32(cin), coutp = bf ? pad64(cout) : pad32(cout);
     const int oh = stride == 2 ? (height + 1) / 2 : height, ow = stride == 2 ? (width + 1) / 2 : width;
-    std::vector<char> packed(bf ? esa::packed_weight_bytes_bf(coutp, cinp, k) : esa::packed_weight_bytes(coutp, cinp, k), 0);
+    std::vector<char> packed(bf ? esa::packed_weight_bytes_bf(coutp, cinp, k) : x6 ? esa::packed_weight_bytes_x6(coutp, cinp, k)
+                                                                                    : esa::packed_weight_bytes(coutp, cinp, k), 0);
     if (bf) esa::pack_conv_weights_bf(w, cout, cin, k, coutp, cinp, packed.data());
+    else if (x6) esa::pack_conv_weights_x6(w, cout, cin, k, coutp, cinp, packed.data());
     else esa::pack_conv_weights(w, cout, cin, k, coutp, cinp, packed.data());
     std::vector<float> bias(coutp, 0.f);
     std::copy(b, b + cout, bias.begin());
@@ -2152,18 +2170,17 @@ int esahrnet_op_conv_ex(const void* x_dev, int n, int cin, int height, int width
     const size_t xb = (size_t)n * height * width * cinp * eb, yb = (size_t)n * oh * ow * coutp * eb;
     if (hipMalloc(&xs, xb) != hipSuccess || hipMalloc(&ys, yb) != hipSuccess ||
         (res_dev && hipMalloc(&rs, yb) != hipSuccess)) { cleanup(); return fail("op_conv: hipMalloc failed"); }
-    auto to_internal = bf ? esa::launch_nchw_to_bf : esa::launch_nchw_to_sb;
-    rc = to_internal(static_cast<const float*>(x_dev), n, cin, height, width, static_cast<char*>(xs), cinp, stream);
-    if (!rc && res_dev) rc = to_internal(static_cast<const float*>(res_dev), n, cout, oh, ow, static_cast<char*>(rs), coutp, stream);
+    rc = esa::launch_nchw_to_fmt(fmt, static_cast<const float*>(x_dev), n, cin, height, width, static_cast<char*>(xs), cinp, stream);
+    if (!rc && res_dev) rc = esa::launch_nchw_to_fmt(fmt, static_cast<const float*>(res_dev), n, cout, oh, ow, static_cast<char*>(rs), coutp, stream);
     if (!rc) {
         esa::ConvParams p{};
         p.x = static_cast<const char*>(xs); p.y = static_cast<char*>(ys); p.res = static_cast<const char*>(rs);
         p.w = static_cast<const uint4*>(dw); p.bias = static_cast<const float*>(db);
         p.N = n; p.H = height; p.W = width; p.OH = oh; p.OW = ow; p.Cinp = cinp; p.Coutp = coutp; p.relu = relu;
-        p.bf = bf ? 1 : 0;
+        p.fmt = fmt;
         rc = esa::launch_conv(p, k, stride, stream);
     }
-    if (!rc) rc = (bf ? esa::launch_bf_to_nchw : esa::launch_sb_to_nchw)(static_cast<const char*>(ys), n, cout, oh, ow, coutp, static_cast<float*>(y_dev), stream);
+    if (!rc) rc = esa::launch_fmt_to_nchw(fmt, static_cast<const char*>(ys), n, cout, oh, ow, coutp, static_cast<float*>(y_dev), stream);
     hipError_t se = hipStreamSynchronize(stream);
     cleanup();
     if (rc) return fail("op_conv: launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -2179,8 +2196,9 @@ int esahrnet_op_fuse(const void* const* xs_dev, const int* hs, const int* ws, in
 int esahrnet_op_fuse_ex(const void* const* xs_dev, const int* hs, const int* ws, int nterms, int n, int c,
                         int height, int width, int relu, void* y_dev, int precision, esahrnet_stream stream_) {
     if (!xs_dev || !hs || !ws || !y_dev || nterms < 1 || nterms > 4) return fail("op_fuse: bad argument");
-    if (precision != 0 && precision != 1) return fail("op_fuse: precision %d", precision);
+    if (precision < 0 || precision > 2) return fail("op_fuse: precision %d", precision);
     const bool bf = precision == 1;
+    const int fmt = bf ? esa::FMT_BF : precision == 2 ? esa::FMT_F32 : esa::FMT_SB;
     const int eb = bf ? 2 : 4;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int cp = bf ? pad64(c) : pad32(c);
@@ -2188,16 +2206,16 @@ int esahrnet_op_fuse_ex(const void* const* xs_dev, const int* hs, const int* ws,
     auto cleanup = [&]() { for (void* p : bufs) if (p) (void)hipFree(p); };
     int rc = 0;
     esa::FuseParams p{};
-    p.nterms = nterms; p.N = n; p.H = height; p.W = width; p.Cp = cp; p.relu = relu; p.bf = bf ? 1 : 0;
+    p.nterms = nterms; p.N = n; p.H = height; p.W = width; p.Cp = cp; p.relu = relu; p.fmt = fmt;
     for (int i = 0; i < nterms && !rc; ++i) {
         if (hipMalloc(&bufs[i], (size_t)n * hs[i] * ws[i] * cp * eb) != hipSuccess) { cleanup(); return fail("op_fuse: hipMalloc failed"); }
-        rc = (bf ? esa::launch_nchw_to_bf : esa::launch_nchw_to_sb)(static_cast<const float*>(xs_dev[i]), n, c, hs[i], ws[i], static_cast<char*>(bufs[i]), cp, stream);
+        rc = esa::launch_nchw_to_fmt(fmt, static_cast<const float*>(xs_dev[i]), n, c, hs[i], ws[i], static_cast<char*>(bufs[i]), cp, stream);
         p.x[i] = static_cast<const char*>(bufs[i]); p.h[i] = hs[i]; p.w[i] = ws[i];
     }
     if (!rc && hipMalloc(&bufs[4], (size_t)n * height * width * cp * eb) != hipSuccess) { cleanup(); return fail("op_fuse: hipMalloc failed"); }
     p.y = static_cast<char*>(bufs[4]);
     if (!rc) rc = esa::launch_fuse(p, stream);
-    if (!rc) rc = (bf ? esa::launch_bf_to_nchw : esa::launch_sb_to_nchw)(p.y, n, c, height, width, cp, static_cast<float*>(y_dev), stream);
+    if (!rc) rc = esa::launch_fmt_to_nchw(fmt, p.y, n, c, height, width, cp, static_cast<float*>(y_dev), stream);
     hipError_t se = hipStreamSynchronize(stream);
     cleanup();
     if (rc) return fail("op_fuse: launch failed: %s", hipGetErrorString((hipError_t)rc));

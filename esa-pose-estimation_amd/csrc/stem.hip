@@ -56,8 +56,14 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, long long total
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = relu1(acc[i]);
     }
-    if (p.bf) {
+    if (p.fmt == FMT_BF) {
         *reinterpret_cast<uint4*>(p.y + (((size_t)(n * p.H + y) * p.W + x) * p.cout) * 2 + c8 * 16) = pack8_bf16(acc);
+        return;
+    }
+    if (p.fmt == FMT_F32) {
+        float* o = reinterpret_cast<float*>(p.y) + ((size_t)(n * p.H + y) * p.W + x) * p.cout + c8 * 8;
+        *reinterpret_cast<f32x4*>(o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
         return;
     }
     uint4 hi, lo;
@@ -141,8 +147,12 @@ __global__ __launch_bounds__(256) void stem1_kernel(StemParams p, int xgroups, l
 #pragma unroll
             for (int i = 0; i < 8; ++i) { ps[i] += acc[i]; pm[i] = fmaxf(pm[i], acc[i]); }
         }
-        if (p.bf) {
+        if (p.fmt == FMT_BF) {
             *reinterpret_cast<uint4*>(p.y + (((size_t)(n * p.H + y) * p.W + x) * p.cout) * 2 + c8 * 16) = pack8_bf16(acc);
+        } else if (p.fmt == FMT_F32) {
+            float* o = reinterpret_cast<float*>(p.y) + ((size_t)(n * p.H + y) * p.W + x) * p.cout + c8 * 8;
+            *reinterpret_cast<f32x4*>(o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
         } else {
             uint4 hi, lo;
             split8(acc, hi, lo);
@@ -178,7 +188,7 @@ int stem_pool_slabs(int cin, int cout, int H, int W) {
 // conv1 as launch_stem computes it + per-slab (sum, max) of every channel into pool[N][slabs][cout][2]
 int launch_stem_pool(const StemParams& p, float* pool, hipStream_t stream) {
     const int slabs = stem_pool_slabs(p.cin, p.cout, p.H, p.W);
-    if (!slabs || !pool || p.bf || (long long)p.N * p.H > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    if (!slabs || !pool || p.fmt != FMT_SB || (long long)p.N * p.H > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const int xgroups = (p.W + STEM_PX - 1) / STEM_PX;
     const dim3 grid((unsigned)((xgroups * (p.cout >> 3) + 255) / 256), (unsigned)(p.N * p.H));
     hipLaunchKernelGGL(stem1_kernel<true>, grid, dim3(256), 0, stream, p, xgroups, 0LL, pool);

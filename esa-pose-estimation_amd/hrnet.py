@@ -32,7 +32,9 @@ logger = logging.getLogger(__name__)
 BN_MOMENTUM = 0.01           # models/seg_hrnet.py:23 (irrelevant at inference, kept for parity)
 
 
-PRECISIONS = {"bf16x3": 0, "split-bf16": 0, "fp32": 0, "bf16": 1, 0: 0, 1: 1}
+# "fp32" is the fp32-grade bf16x6 mode (the reference's arithmetic class, BASELINE configs[1]); "bf16x3" (split-bf16,
+# ~16 significand bits) is an explicitly named opt-in and NOT an alias of fp32
+PRECISIONS = {"fp32": 2, "bf16x6": 2, "bf16x3": 0, "split-bf16": 0, "bf16": 1, 0: 0, 1: 1, 2: 2}
 
 
 def _cfg_struct(config, cin: int, num_keypoints: int, variant: int = 0, precision=0) -> _lib.Cfg:
@@ -90,16 +92,18 @@ class HighResolutionNet(nn.Module):
     CIN = 3                  # models/seg_hrnet.py:265
     NUM_KEYPOINTS = 32       # models/seg_hrnet.py:324
     VARIANT = 0              # 1 = seg_hrnet3.py (CBAM)
+    DEFAULT_PRECISION = "fp32"   # the reference computes in fp32 (models/seg_hrnet.py:425-473): fp32-grade bf16x6 by default
 
     def __init__(self, config, **kwargs):
         super().__init__()
         cin = int(kwargs.pop("cin", self.CIN))
         k = int(kwargs.pop("num_keypoints", self.NUM_KEYPOINTS))
         self._cin, self._k = cin, k
-        # precision: "bf16x3" (default; fp32-grade split-bf16, BASELINE configs[1]) or "bf16" (single-pass bf16
-        # storage / fp32 accumulate, BASELINE configs[3]) — include/esahrnet.h esahrnet_cfg.precision
+        # precision (include/esahrnet.h esahrnet_cfg.precision): "fp32" = "bf16x6" (default: fp32-grade, BASELINE
+        # configs[1] / [2]), "bf16x3" (split-bf16, ~16 significand bits: explicit opt-in, ~1.7x faster), "bf16"
+        # (single-pass bf16 storage / fp32 accumulate, BASELINE configs[3])
         self._cfg_struct = _cfg_struct(config, cin, k, int(kwargs.pop("variant", self.VARIANT)),
-                                       kwargs.pop("precision", 0))
+                                       kwargs.pop("precision", self.DEFAULT_PRECISION))
         object.__setattr__(self, "_rt", _Runtime(self._cfg_struct))
         self._descs = self._rt.conv_descs()
         for d in self._descs:

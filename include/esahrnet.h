@@ -52,8 +52,12 @@ typedef struct esahrnet_cfg {
                                     BasicBlock and on the 64-ch pre-BN stem skip, 3x3 last_layer[0],
                                     output_layer over [heatmaps, skip]; models/seg_hrnet3.py)         */
     int32_t precision;           /* arithmetic of the convolutions (not a reference knob: BASELINE.json configs):
-                                    0: split-bf16 hi/lo operands, 3 MFMAs per product, f32 accumulate — fp32-grade
-                                       (heatmap L_inf ~1e-5), the mode of configs[1] / configs[2];
+                                    2: "bf16x6" — fp32-grade, THE MODE OF configs[1] / configs[2] (the reference computes in
+                                       fp32, models/seg_hrnet.py:425-473): f32 NHWC activations, every operand split exactly
+                                       into three bf16 terms, 6 MFMAs per product, f32 accumulate; error vs fp64 at or below
+                                       that of an f32 FMA chain; variant 0 only;
+                                    0: "bf16x3" — split-bf16 hi/lo operands (~16 significand bits), 3 MFMAs per product, f32
+                                       accumulate: heatmap L_inf ~1e-5 of the heat-map scale; opt-in fast mode, NOT fp32;
                                     1: bf16 activations and weights stored ONCE (half the bytes, one MFMA per
                                        product), f32 accumulate, f32 folded-BN bias epilogue — configs[3]
                                        (heatmap L_inf ~1e-2); variant 0 only                                   */
@@ -121,7 +125,7 @@ int esahrnet_keypoints_ex(const void* heat_dev, int n, int k, int height, int wi
  * those instead of sweeping n*K*height*width floats; its results are bit-identical to esahrnet_keypoints_ex on the same
  * heat-maps (same ordering of ties and NaNs, same refinement).  Replaces: `net(x)` followed by get_final / the host peak
  * search (val.py:151-166, inference.py:136-152).
- * esahrnet_partial_tiles: ntiles for a crop size; 0 = this handle cannot (bf16 precision, seg_hrnet3, VALU output layer):
+ * esahrnet_partial_tiles: ntiles for a crop size; 0 = this handle cannot (seg_hrnet3, a VALU output layer):
  * use esahrnet_forward + esahrnet_keypoints.  part_dev == NULL makes esahrnet_forward_partials plain esahrnet_forward. */
 int esahrnet_partial_tiles(esahrnet_handle h, int height, int width, int* ntiles);
 int esahrnet_forward_partials(esahrnet_handle h, const void* x_dev, int n, int height, int width, void* heat_dev,
@@ -190,7 +194,7 @@ int esahrnet_op_conv(const void* x_dev, int n, int cin, int height, int width,
 int esahrnet_op_fuse(const void* const* xs_dev, const int* hs, const int* ws, int nterms,
                      int n, int c, int height, int width, int relu, void* y_dev,
                      esahrnet_stream stream);
-/* The same two operators in the arithmetic of esahrnet_cfg.precision (0: split-bf16, 1: single bf16): inputs are
+/* The same two operators in the arithmetic of esahrnet_cfg.precision (0: split-bf16, 1: single bf16, 2: bf16x6): inputs are
  * converted to the internal format, the kernel of that mode runs, the result is converted back to f32. */
 int esahrnet_op_conv_ex(const void* x_dev, int n, int cin, int height, int width,
                         const float* w, const float* b, int cout, int k, int stride, int relu,

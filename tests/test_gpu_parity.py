@@ -140,6 +140,7 @@ def test_op_fuse_matches_torch_cpu(env):
 
 # ------------------------------------------------------------------------------------- full net
 def _build(env, variant, widths, seed, gain=0.5, **kw):
+    kw.setdefault("precision", "bf16x3")     # the tests of this file pin the split-bf16 kernels; fp32 mode: test_gpu_fp32.py
     mod = env[variant]
     net = mod.get_seg_model(env["config"].make_config(widths=widths), **kw)
     sd = env["synth"].make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=seed, gain=gain)

@@ -52,7 +52,8 @@ __global__ void dot_kernel(const uint16_t* A, const uint16_t* B, const float* Af
     const int lane = threadIdx.x, prob = blockIdx.x;
     const int ks = K / 32;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (MODE == 0) {
+    if (MODE == 7 || MODE == 8) {
+    } else if (MODE == 0) {
         // v_mfma_f32_16x16x4_f32: lane l holds A[l&15][k = l>>4], B[k = l>>4][l&15]
         for (int k4 = 0; k4 < K / 4; ++k4) {
             const float a = Af[((size_t)prob * 16 + (lane & 15)) * K + k4 * 4 + (lane >> 4)];
@@ -83,6 +84,37 @@ __global__ void dot_kernel(const uint16_t* A, const uint16_t* B, const float* Af
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+        }
+    }
+    if (MODE == 7 || MODE == 8) {
+        // MODE 7: groups of 3 K-steps (the three ky taps of one kx phase) summed in a FRESH accumulator — the fifteen
+        // low-order products first, the three main ones last — and added to the running sum by one VALU add per group.
+        // MODE 8: the same with groups of 9 K-steps (a whole 32-channel chunk of a 3x3).
+        const int GRP = MODE == 7 ? 3 : 9;
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const size_t term = (size_t)ks * 64 * 8;
+        const uint16_t* a0 = A + (size_t)prob * 3 * term;
+        const uint16_t* b0 = B + (size_t)prob * 3 * term;
+        for (int k0 = 0; k0 < ks; k0 += GRP) {
+            f32x4 tmp = {0.f, 0.f, 0.f, 0.f};
+            for (int pass = 0; pass < 2; ++pass)
+                for (int kk = k0; kk < k0 + GRP && kk < ks; ++kk) {
+                    bf16x8 a[3], b[3];
+                    for (int t = 0; t < 3; ++t) {
+                        a[t] = *reinterpret_cast<const bf16x8*>(a0 + t * term + ((size_t)kk * 64 + lane) * 8);
+                        b[t] = *reinterpret_cast<const bf16x8*>(b0 + t * term + ((size_t)kk * 64 + lane) * 8);
+                    }
+                    if (pass == 0) {
+                        tmp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], tmp, 0, 0, 0);
+                        tmp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], tmp, 0, 0, 0);
+                        tmp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], tmp, 0, 0, 0);
+                        tmp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], tmp, 0, 0, 0);
+                        tmp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], tmp, 0, 0, 0);
+                    } else {
+                        tmp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], tmp, 0, 0, 0);
+                    }
+                }
+            for (int r = 0; r < 4; ++r) acc[r] += tmp[r];
         }
     }
     // D[row = 4*(lane>>4) + r][col = lane&15]
@@ -138,12 +170,28 @@ int main() {
             Stat st;
             for (size_t i = 0; i < ref.size(); ++i) add(st, seq[i], ref[i], sabs[i]);
             show("host sequential f32 fmaf", st);
+            {   // 16 interleaved f32 partial sums (a vectorised CPU dot product), combined pairwise
+                Stat sb;
+                for (int p = 0; p < P; ++p)
+                    for (int r = 0; r < 16; ++r)
+                        for (int c = 0; c < 16; ++c) {
+                            float part[16] = {0};
+                            for (int k = 0; k < K; ++k)
+                                part[k & 15] = fmaf(Af[((size_t)p * 16 + r) * K + k], Bf[((size_t)p * 16 + c) * K + k], part[k & 15]);
+                            for (int w = 8; w >= 1; w >>= 1)
+                                for (int i = 0; i < w; ++i) part[i] += part[i + w];
+                            add(sb, part[0], ref[(size_t)p * 256 + r * 16 + c], sabs[(size_t)p * 256 + r * 16 + c]);
+                        }
+                show("host f32, 16 partial sums", sb);
+            }
             std::vector<float> D((size_t)P * 256);
             auto run = [&](int mode, const char* name) {
                 switch (mode) {
                     case 0: dot_kernel<0><<<P, 64>>>(dA, dB, dAf, dBf, dD, K); break;
                     case 3: dot_kernel<3><<<P, 64>>>(dA, dB, dAf, dBf, dD, K); break;
                     case 6: dot_kernel<6><<<P, 64>>>(dA, dB, dAf, dBf, dD, K); break;
+                    case 7: dot_kernel<7><<<P, 64>>>(dA, dB, dAf, dBf, dD, K); break;
+                    case 8: dot_kernel<8><<<P, 64>>>(dA, dB, dAf, dBf, dD, K); break;
                     default: dot_kernel<9><<<P, 64>>>(dA, dB, dAf, dBf, dD, K); break;
                 }
                 hipDeviceSynchronize();
@@ -173,6 +221,8 @@ int main() {
                 run(3, trunc ? "bf16 x3 (2 terms, truncated)" : "bf16 x3 (2 terms, RNE)");
                 run(6, trunc ? "bf16 x6 (3 terms, truncated)" : "bf16 x6 (3 terms, RNE)");
                 run(9, trunc ? "bf16 x9 (3 terms, truncated)" : "bf16 x9 (3 terms, RNE)");
+                if (!trunc) run(7, "bf16 x6, fresh acc per 3 K-steps");
+                if (!trunc) run(8, "bf16 x6, fresh acc per 9 K-steps");
             }
             hipFree(dAf); hipFree(dBf); hipFree(dD); hipFree(dA); hipFree(dB);
         }
