@@ -9,10 +9,12 @@ resident in HBM:  x [B,1,256,256] f32 -> HRNet forward (seg_hrnet2 topology, wid
 -> [B,11,256,256] heatmaps -> fused arg-max + sub-pixel refine -> [B,11,3] keypoints
 (+ for N>1 the RCCL all-gather of the keypoints, the path's only exchange).  B = 32 per GPU
 (BASELINE.json configs[1]); weak scaling: N GPUs process N*32 crops per step (configs[2] at N=8).
+Arithmetic: the fp32-grade mode (precision "fp32" = bf16x6, include/esahrnet.h) — configs[1] says fp32; the faster
+split-bf16 mode is an `extras` line, never `value`.
 
 One JSON line on stdout (rank 0), carrying also
-  "roofline":     dominant kernel (3x3 stride-1 split-bf16 MFMA convolution) — algorithmic FLOPs
-                  per launch / HIP-event duration per launch, against the bf16x3 MFMA peak;
+  "roofline":     dominant kernel (the 3x3 stride-1 bf16x6 MFMA convolution, conv_x6.hip) — algorithmic FLOPs
+                  per launch / HIP-event duration per launch, against the bf16x6 ceiling 2500/6 TFLOP/s;
   "cpu_baseline": the CPU oracle (torch-CPU restatement of the reference forward + numpy
                   post-processing) timed on this box's host cores on a bounded sample: batch 1 on all
                   cores (the headline row), batch 1 on one thread and batch 32 on all cores (BASELINE.md §2);
@@ -45,6 +47,21 @@ import torch.distributed as dist  # noqa: E402
 # ALGORITHMIC FLOP/s of the convolution kernels is 2500/3 TFLOP/s; the single-pass bf16 mode prices against 2500.
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 3.0
+# fp32-grade mode ("fp32" = bf16x6: exact 3-term bf16 split, 6 MFMA FLOPs per algorithmic FLOP)
+PEAK_BF16X6_TFLOPS = PEAK_BF16_TFLOPS / 6.0
+DTYPES = {
+    "fp32": "bf16x6 (fp32-grade: every f32 operand split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, f32 accumulate; "
+            "f32 NHWC activations; f32 VALU stem conv1 / output layer) — heat-maps closer to fp64 than the fp32 CPU reference",
+    "bf16x3": "bf16x3 (split-bf16 MFMA, ~16 significand bits per operand, f32 accumulate; f32 VALU stem/head) — NOT fp32",
+    "bf16": "bf16 (single-pass bf16 MFMA, f32 accumulate, f32 bias epilogue; f32 VALU stem conv1 / output layer)",
+}
+PEAKS = {"fp32": PEAK_BF16X6_TFLOPS, "bf16x3": PEAK_BF16X3_TFLOPS, "bf16": PEAK_BF16_TFLOPS}
+PEAK_NOTES = {
+    "fp32": "bf16x6: 6 bf16 MFMA FLOPs per algorithmic FLOP -> ceiling 2500/6 = 416.7 TFLOP/s (2.65 x the f32 vector/matrix peak)",
+    "bf16x3": "split-bf16: 3 bf16 MFMA FLOPs per algorithmic FLOP -> ceiling 2500/3 TFLOP/s",
+    "bf16": ("single-pass bf16: one MFMA FLOP per algorithmic FLOP -> ceiling 2500 TFLOP/s; layer-by-layer bf16 "
+             "is HBM-bound on the wide-resolution branches, hence both fractions (compulsory bytes / 8 TB/s)"),
+}
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0
 
@@ -59,6 +76,8 @@ def parse():
     ap.add_argument("--workload", default="w32", choices=["w32", "w48-bf16", "w48"],
                     help="w32: BASELINE configs[1] (headline); w48-bf16: configs[3]; w48: the same net in split-bf16")
     ap.add_argument("--variant", default="seg_hrnet2", choices=["seg_hrnet2", "seg_hrnet", "seg_hrnet3"])
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16"],
+                    help="default: fp32 (fp32-grade bf16x6, BASELINE configs[1]); w48-bf16: bf16; seg_hrnet3: bf16x3")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -202,17 +221,16 @@ def roofline_leg(net, x, profile_steps, precision):
             traffic = json.load(open(tpath)).get(dominant)
         except Exception:
             traffic = None
-    bf16 = precision == "bf16"
-    peak = PEAK_BF16_TFLOPS if bf16 else PEAK_BF16X3_TFLOPS
+    peak = PEAKS[precision]
     roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc pass of this workload, HBM bytes per launch; "
+                              "not measured in this run)" if traffic is not None else None,
             "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
             "frac_of_f32_peak": round(ach / PEAK_F32_TFLOPS, 4),
             "algorithmic_gbps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / PEAK_HBM_GBPS, 4),
-            "peak_note": ("single-pass bf16: one MFMA FLOP per algorithmic FLOP -> ceiling 2500 TFLOP/s; layer-by-layer bf16 "
-                          "is HBM-bound on the wide-resolution branches, hence both fractions (compulsory bytes / 8 TB/s)")
-            if bf16 else "split-bf16: 3 bf16 MFMA FLOPs per algorithmic FLOP -> ceiling 2500/3 TFLOP/s"}
+            "peak_note": PEAK_NOTES[precision]}
     tot_ms = sum(v["ms"] for v in groups.values())
     breakdown = {k: {"launches": v["launches"], "ms": round(v["ms"], 4), "share": round(v["ms"] / tot_ms, 4),
                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
@@ -249,8 +267,7 @@ def side_workload(tag, variant, widths, precision, batch, hw, dev, steps, warmup
     value = batch * steps / elapsed
     res = {"workload": tag, "value": round(value, 1), "unit": "crops/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
            "batch": batch, "steps": steps, "hip_graph": graph is not None, "launches": roof["launches_per_forward"],
-           "dtype": "bf16 (single-pass bf16 MFMA, f32 accumulate, f32 bias epilogue)" if precision == "bf16"
-           else "bf16x3 (split-bf16 MFMA, f32 accumulate)",
+           "dtype": DTYPES[precision],
            "algorithmic_gflop_per_crop": round(flops_crop / 1e9, 3),
            "whole_net_algorithmic_tflops": round(value * flops_crop / 1e12, 2),
            "roofline": roof, "kernel_breakdown": breakdown}
@@ -279,7 +296,7 @@ def main():
     from esa_pose_estimation_amd import inference, parallel, synth
     w48 = args.workload.startswith("w48")
     widths = (48, 96, 192, 384) if w48 else (32, 64, 128, 256)
-    precision = "bf16" if args.workload == "w48-bf16" else "bf16x3"
+    precision = args.precision or ("bf16" if args.workload == "w48-bf16" else "bf16x3" if (w48 or args.variant == "seg_hrnet3") else "fp32")
     B = args.batch or (64 if w48 else 32)
     hw = args.hw or (384 if w48 else 256)
     net, sd = build_net(args.variant, widths, precision, dev)
@@ -311,7 +328,7 @@ def main():
             roof, breakdown = roofline_leg(net, x, args.profile_steps, precision)
 
         extras = None
-        if rank == 0 and world == 1 and not args.no_extras and args.workload == "w32" and args.variant == "seg_hrnet2":
+        if rank == 0 and world == 1 and not args.no_extras and args.workload == "w32" and args.variant == "seg_hrnet2" and precision == "fp32":
             extras = {}
             # ---- batch-1 latency (val.py:112 calls the net once per image) --------------------------------------
             x1 = x[:1].clone()
@@ -354,7 +371,10 @@ def main():
                                        "ms_per_step": round(el / args.sustained_steps * 1e3, 4),
                                        "seconds": round(el, 2)}
             # ---- BASELINE configs[3] and the production network ----------------------------------------------------
-            for key, a in (("config3_w48_384_bf16", ("HRNet-W48 384x384 batch 64, bf16 storage / f32 accumulate (BASELINE configs[3])",
+            for key, a in (("w32_bf16x3_opt_in", ("the headline workload in the split-bf16 fast mode (precision='bf16x3': NOT fp32; "
+                                                  "heat-map error ~1e-5 of scale instead of ~5e-7)",
+                                                  "seg_hrnet2", (32, 64, 128, 256), "bf16x3", 32, 256)),
+                           ("config3_w48_384_bf16", ("HRNet-W48 384x384 batch 64, bf16 storage / f32 accumulate (BASELINE configs[3])",
                                                      "seg_hrnet2", (48, 96, 192, 384), "bf16", 64, 384)),
                            ("seg_hrnet3", ("seg_hrnet3 (CBAM, val.py:380) W32 256x256 batch 32, 30 keypoints",
                                            "seg_hrnet3", (32, 64, 128, 256), "bf16x3", 32, 256))):
@@ -382,8 +402,7 @@ def main():
             "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 (single-pass bf16 MFMA, f32 accumulate, f32 bias epilogue; f32 VALU stem conv1 / output layer)"
-            if precision == "bf16" else "bf16x3 (split-bf16 MFMA, f32 accumulate; f32 VALU stem/head)",
+            "dtype": DTYPES[precision],
             "data": "synthetic",
             "config": {"workload": f"{args.variant} HRNet-{wname} {hw}x{hw}, batch {B}/GPU, {K} keypoints, "
                                    f"fp32 NCHW in -> heatmaps -> keypoints (BASELINE configs[{cfg_idx}])",

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libesahrnet.so")
-SOURCES = ["conv_mfma.hip", "conv_s2c32.hip", "conv_x6.hip", "conv1x1.hip", "stem.hip", "stem_fused.hip", "bblock32.hip", "cbam.hip", "crops.hip", "fuse.hip", "head.hip", "head_fused.hip", "head_fused2.hip", "head_fused_bf.hip", "head_gather.hip", "head_t.hip", "keypoints.hip", "layout.hip", "plan.hip", "pnp_host.hip"]
+SOURCES = ["conv_mfma.hip", "conv_s2c32.hip", "conv_x6.hip", "conv1x1.hip", "stem.hip", "stem_fused.hip", "bblock32.hip", "cbam.hip", "crops.hip", "fuse.hip", "head.hip", "head_fused.hip", "head_fused2.hip", "head_fused_bf.hip", "head_gather.hip", "head_t.hip", "head_x6.hip", "keypoints.hip", "layout.hip", "plan.hip", "pnp_host.hip"]
 HEADERS = ["kernels.h", "sb.h", "conv_cfg.h", "devstate.h", os.path.join("..", "..", "include", "esahrnet.h")]
 
 

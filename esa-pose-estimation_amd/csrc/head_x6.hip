@@ -1,0 +1,320 @@
+// head_x6.hip — the whole of last_layer[0..5] in one kernel for the fp32-grade mode (f32 NHWC tensors, bf16x6
+// arithmetic, conv_x6.hip), never materialising the 480-channel tensors:
+//
+//   h0 = ReLU( W0·x0  +  sum_{b=1..3} bilinear_up(t_b)  +  bias0 )        (480 ch @ H/2)
+//   h3 = ReLU( W3·h0 + bias3 )                                            (K   ch @ H/2)
+//
+// Replaces (reference): the three F.upsample + torch.cat of models/seg_hrnet.py:461-466 and last_layer[0..5]
+// (1x1 480->480 + BN + ReLU, 1x1 480->K + BN + ReLU, :313-329).  The 1x1 convolution is pushed through the (linear)
+// bilinear up-sampling: t_b = W_b·x_b is computed on branch b's own grid by conv_x6 and only interpolated here (f32
+// VALU, ATen's align_corners=False weights); W_0 acts on the full-resolution branch directly.  Same structure as
+// head_fused.hip (the split-bf16 mode's first-generation head) — one workgroup = 16x16 pixels = 16 waves, one 16-pixel
+// row per wave, per 32-channel chunk of h0:
+//   (1) a[2 M-tiles] = W0[chunk]·x0 — six MFMAs per tile and 32 input channels on the three exact bf16 terms of x0
+//       (registers for the whole kernel) and of W0 (LDS-staged), low-order products first;
+//   (2) + bias0 + the bilinear taps of t_1..t_3 from an LDS-staged f32 tile of this chunk;
+//   (3) ReLU, exact 3-term split — the accumulator layout (lane = pixel, 4+4 consecutive channels) IS the B fragment of
+//       conv_x6's K order (x6_chan_of_k), so h0 goes straight back into the matrix cores: six MFMAs per K-tile into a
+//       FRESH accumulator, added to acc3 by one VALU add per chunk (tools/ubench/x6_numerics.hip: the rounding of a
+//       long MFMA chain is what separates a bf16x6 sum from a blocked f32 sum);
+// h0 never leaves the register file.  In the op-by-op plan these tensors cost 4 GB of HBM traffic per batch-32 step.
+#include "devstate.h"
+#include "kernels.h"
+#include "sb.h"
+
+namespace esa {
+namespace {
+
+constexpr int HT = 16;                 // tile width (pixels)
+constexpr int HTY = 8;                 // tile height: one row per wave, 8 waves (256 VGPRs each: the three-term fragments of
+                                       // x0, W0, W3 and h0 do not fit the 128 of head_fused's 16-wave workgroup)
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+constexpr int PIXB = 144;              // LDS pixel pitch of the staged f32 t-tiles (128 B + 16 B pad)
+constexpr int RMAX1 = 11, RMAX2 = 7, RMAX3 = 5;   // max source-region width per low-res branch (16 output columns)
+constexpr int RMAY1 = 7, RMAY2 = 5, RMAY3 = 4;    // max source-region height (8 output rows)
+constexpr int REG_PIX = RMAY1 * RMAX1 + RMAY2 * RMAX2 + RMAY3 * RMAX3;   // 132 pixels
+constexpr int BUF_BYTES = REG_PIX * PIXB;                                // 28080 B per buffer
+
+// 8 floats (two accumulator quads: K order x6_chan_of_k) -> three bf16x8 fragments, v = t0 + t1 + t2 exactly
+__device__ __forceinline__ void x6_split8(const float v[8], bf16x8 out[3]) {
+    u32x4 t[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x2 a = {v[2 * k], v[2 * k + 1]};
+        const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
+        const f32x2 r = {a[0] - __uint_as_float(h << 16), a[1] - __uint_as_float(h & 0xffff0000u)};
+        const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+        const f32x2 q = {r[0] - __uint_as_float(m << 16), r[1] - __uint_as_float(m & 0xffff0000u)};
+        t[0][k] = h; t[1][k] = m; t[2][k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(q, bf16x2));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = __builtin_bit_cast(bf16x8, t[i]);
+}
+// six products of one 16x16x32 tile pair into `d`: the five low-order ones first, a0*b0 last
+__device__ __forceinline__ f32x4 x6_mma(const bf16x8 a[3], const bf16x8 b[3], f32x4 d) {
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], d, 0, 0, 0);
+    return d;
+}
+
+struct LerpF {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ LerpF lerp_false(int dst, int in, int out) {     // align_corners=False
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    LerpF r;
+    r.i0 = min((int)src, in - 1);
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+constexpr int HTHREADS = 512;          // 8 waves
+
+template <int NCH0, int M3>
+__global__ __launch_bounds__(HTHREADS, 2) void head_x6_kernel(HeadParams p, int tiles_x, int tiles_y) {
+    constexpr int WFR = 2 * NCH0 * 3 + M3 * 3;          // 1-KB weight fragments per chunk (W0 then W3), three terms each
+    constexpr int WBYTES = WFR * 1024;
+    constexpr int STRIDE = BUF_BYTES + WBYTES;          // one LDS buffer: t tiles, then weights
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = lane & 15, q = lane >> 4;
+    int b_ = blockIdx.x;
+    const int tx = b_ % tiles_x; b_ /= tiles_x;
+    const int ty = b_ % tiles_y;
+    const int n = b_ / tiles_y;
+    const int oy0 = ty * HTY, ox0 = tx * HT;
+    const int nchunks = p.Ctp >> 5;
+
+    // ---- source regions of the three low-resolution terms (workgroup-uniform) ---------------
+    int ry0[3], rx0[3], rh[3], rw[3], rbase[3];
+    {
+        int base = 0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const LerpF a = lerp_false(oy0, p.th[b], p.H), e = lerp_false(min(oy0 + HTY - 1, p.H - 1), p.th[b], p.H);
+            const LerpF c = lerp_false(ox0, p.tw[b], p.W), d = lerp_false(min(ox0 + HT - 1, p.W - 1), p.tw[b], p.W);
+            ry0[b] = a.i0; rh[b] = e.i1 - a.i0 + 1;
+            rx0[b] = c.i0; rw[b] = d.i1 - c.i0 + 1;
+            rbase[b] = base;
+            base += rh[b] * rw[b];
+        }
+    }
+    const int npix_stage = rbase[2] + rh[2] * rw[2];          // <= REG_PIX (validated on the host)
+
+    // ---- staging map: unit u = it*1024 + tid -> staged pixel s = u>>3, 16-B piece j = u&7 -------
+    constexpr int SIT = (REG_PIX * 8 + HTHREADS - 1) / HTHREADS;           // 2
+    const char* sg[SIT];
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+        const int s_ = it * (HTHREADS / 8) + (tid >> 3);
+        sg[it] = nullptr;
+        if (s_ < npix_stage) {
+            const int b = s_ >= rbase[2] ? 2 : (s_ >= rbase[1] ? 1 : 0);
+            const int r = s_ - rbase[b];
+            const int yy = ry0[b] + r / rw[b], xx = rx0[b] + r % rw[b];
+            sg[it] = p.t[b] + (((size_t)n * p.th[b] + yy) * p.tw[b] + xx) * (size_t)(p.Ctp * 4) + (tid & 7) * 16;
+        }
+    }
+    const int lane_lds = (tid >> 3) * PIXB + (tid & 7) * 16;
+    // weights of one chunk: fragments [W0 m0 c0 t0, t1, t2, ... | W3 m t0, t1, t2], 64 uint4 each
+    constexpr int WIT = (WFR * 64 + HTHREADS - 1) / HTHREADS;     // weight units (16 B) per thread
+    uint4 sr[SIT], wreg[WIT];
+#define HEAD_PREFETCH(CH)                                                                     \
+    {                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < SIT; ++it) {                                  \
+            uint4 v = make_uint4(0, 0, 0, 0);                                                 \
+            if (sg[it]) v = *reinterpret_cast<const uint4*>(sg[it] + (CH) * 128);             \
+            sr[it] = v;                                                                       \
+        }                                                                                     \
+        _Pragma("unroll") for (int wi = 0; wi < WIT; ++wi) {                                  \
+            const int wf = wi * (HTHREADS / 64) + (tid >> 6);      /* fragment index */        \
+            if (wf < WFR) {                                                                   \
+                const uint4* src = wf < 6 * NCH0                                              \
+                    ? p.w0 + ((size_t)(CH) * 6 * NCH0 + wf) * 64 + lane                       \
+                    : p.w3 + ((size_t)(((wf - 6 * NCH0) / 3) * nchunks + (CH)) * 3 + ((wf - 6 * NCH0) % 3)) * 64 + lane; \
+                wreg[wi] = *src;                                                              \
+            }                                                                                 \
+        }                                                                                     \
+    }
+#define HEAD_COMMIT(BUF)                                                                      \
+    {                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < SIT; ++it)                                    \
+            if (sg[it]) *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + it * (HTHREADS / 8) * PIXB + lane_lds) = sr[it]; \
+        _Pragma("unroll") for (int wi = 0; wi < WIT; ++wi)                                    \
+            if (wi * (HTHREADS / 64) + (tid >> 6) < WFR)                                      \
+                *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + BUF_BYTES + (wi * HTHREADS + tid) * 16) = wreg[wi]; \
+    }
+
+    // ---- per-lane constants: this wave's x0 fragment, interpolation coefficients ----------------
+    const int ox = ox0 + px, oy = oy0 + wave;
+    const bool in = ox < p.W && oy < p.H;
+    bf16x8 xf[NCH0][3];
+#pragma unroll
+    for (int c = 0; c < NCH0; ++c) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (in) {       // the two quads of conv_x6's K order: channels 4q .. 4q+3 and 16+4q .. 16+4q+3 of the chunk
+            const float* a = reinterpret_cast<const float*>(p.x0) + (((size_t)n * p.H + oy) * p.W + ox) * (size_t)p.C0p + c * 32 + q * 4;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(a), hi = *reinterpret_cast<const f32x4*>(a + 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = lo[i]; v[4 + i] = hi[i]; }
+        }
+        x6_split8(v, xf[c]);
+    }
+    int o00[3], o01[3], o10[3], o11[3];     // LDS byte offsets of the 4 taps (incl. region base, q*16)
+    float w00[3], w01[3], w10[3], w11[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const LerpF lx = lerp_false(min(ox, p.W - 1), p.tw[b], p.W);
+        const LerpF ly = lerp_false(min(oy, p.H - 1), p.th[b], p.H);
+        const int r0 = (rbase[b] + (ly.i0 - ry0[b]) * rw[b]) * PIXB, r1 = (rbase[b] + (ly.i1 - ry0[b]) * rw[b]) * PIXB;
+        const int c0 = (lx.i0 - rx0[b]) * PIXB + q * 16, c1 = (lx.i1 - rx0[b]) * PIXB + q * 16;
+        o00[b] = r0 + c0; o01[b] = r0 + c1; o10[b] = r1 + c0; o11[b] = r1 + c1;
+        w00[b] = ly.l0 * lx.l0; w01[b] = ly.l0 * lx.l1; w10[b] = ly.l1 * lx.l0; w11[b] = ly.l1 * lx.l1;
+    }
+
+    f32x4 acc3[M3];
+#pragma unroll
+    for (int m = 0; m < M3; ++m) acc3[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    HEAD_PREFETCH(0)
+    HEAD_COMMIT(0)
+    __syncthreads();
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const int buf = cc & 1;
+        if (cc + 1 < nchunks) HEAD_PREFETCH(cc + 1)
+        const char* tb = smem + buf * STRIDE;
+        const char* wb = tb + BUF_BYTES + lane * 16;
+        const f32x4 bias_lo = *reinterpret_cast<const f32x4*>(p.bias0 + cc * 32 + q * 4);
+        const f32x4 bias_hi = *reinterpret_cast<const f32x4*>(p.bias0 + cc * 32 + 16 + q * 4);
+        f32x4 a[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int c = 0; c < NCH0; ++c) {
+                bf16x8 wa[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) wa[t] = *reinterpret_cast<const bf16x8*>(wb + ((m * NCH0 + c) * 3 + t) * 1024);
+                a[m] = x6_mma(wa, xf[c], a[m]);
+            }
+        a[0] += bias_lo;
+        a[1] += bias_hi;
+        f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const f32x4 v00 = *reinterpret_cast<const f32x4*>(tb + o00[b] + m * 64);
+                const f32x4 v01 = *reinterpret_cast<const f32x4*>(tb + o01[b] + m * 64);
+                const f32x4 v10 = *reinterpret_cast<const f32x4*>(tb + o10[b] + m * 64);
+                const f32x4 v11 = *reinterpret_cast<const f32x4*>(tb + o11[b] + m * 64);
+                s[m] += w00[b] * v00 + w01[b] * v01 + w10[b] * v10 + w11[b] * v11;
+                // keep at most one (branch, M-tile)'s 4 taps in flight: 128-VGPR budget at 16 waves
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = relu1(a[0][i] + s[0][i]);
+            v[4 + i] = relu1(a[1][i] + s[1][i]);
+        }
+        bf16x8 hf[3];
+        x6_split8(v, hf);
+#pragma unroll
+        for (int m = 0; m < M3; ++m) {
+            bf16x8 w3[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) w3[t] = *reinterpret_cast<const bf16x8*>(wb + (6 * NCH0 + m * 3 + t) * 1024);
+            acc3[m] += x6_mma(w3, hf, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+        if (cc + 1 < nchunks) {
+            HEAD_COMMIT(buf ^ 1)          // nobody reads buffer buf^1 during this iteration
+            __syncthreads();
+        }
+    }
+#undef HEAD_PREFETCH
+#undef HEAD_COMMIT
+
+    // ---- epilogue: h3 = ReLU(acc3 + bias3) -> f32 [N][H][W][C3p] -----------------------------
+    if (in) {
+        float* o = reinterpret_cast<float*>(p.y) + (((size_t)n * p.H + oy) * p.W + ox) * (size_t)p.C3p;
+#pragma unroll
+        for (int m = 0; m < M3; ++m) {
+            const int co = m * 16 + q * 4;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias3 + co);
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = relu1(acc3[m][i] + bv[i]);
+            *reinterpret_cast<f32x4*>(o + co) = v;
+        }
+        for (int c = M3 * 16 + q * 4; c < p.C3p; c += 16)      // keep the padded channels exact zeros
+            *reinterpret_cast<f32x4*>(o + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <int NCH0, int M3>
+int launch_head_x6_t(const HeadParams& p, hipStream_t stream) {
+    auto kern = head_x6_kernel<NCH0, M3>;
+    const int lds = 2 * (BUF_BYTES + (2 * NCH0 * 3 + M3 * 3) * 1024);
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
+    const int tiles_x = (p.W + HT - 1) / HT, tiles_y = (p.H + HTY - 1) / HTY;
+    const long long nblk = (long long)p.N * tiles_x * tiles_y;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(HTHREADS), lds, stream, p, tiles_x, tiles_y);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+static inline void hx6_lerp_host(int dst, int in, int out, int& i0, int& i1) {
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src < in - 1 ? (int)src : in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+}
+
+bool head_x6_supported(int H, int W, const int th[3], const int tw[3], int C0p, int K) {
+    if (C0p != 32 && C0p != 64) return false;
+    if (K < 1 || K > 32) return false;
+    const int rmx[3] = {RMAX1, RMAX2, RMAX3}, rmy[3] = {RMAY1, RMAY2, RMAY3};
+    for (int b = 0; b < 3; ++b) {
+        for (int o = 0; o < H; o += HTY) {
+            int a0, a1, e0, e1;
+            hx6_lerp_host(o, th[b], H, a0, a1);
+            hx6_lerp_host(o + HTY - 1 < H - 1 ? o + HTY - 1 : H - 1, th[b], H, e0, e1);
+            if (e1 - a0 + 1 > rmy[b]) return false;
+        }
+        for (int o = 0; o < W; o += HT) {
+            int a0, a1, e0, e1;
+            hx6_lerp_host(o, tw[b], W, a0, a1);
+            hx6_lerp_host(o + HT - 1 < W - 1 ? o + HT - 1 : W - 1, tw[b], W, e0, e1);
+            if (e1 - a0 + 1 > rmx[b]) return false;
+        }
+    }
+    return true;
+}
+
+// x0, t[b], y: f32 NHWC; w0 = pack_conv_weights_x6(k = 1) of last_layer[0]'s branch-0 slice [Ctp/16][C0p/32][3][64],
+// w3 = pack_conv_weights_x6(k = 1) of last_layer[3] [M3][Ctp/32][3][64]; the source-region geometry is checked by
+// head_x6_supported
+int launch_head_x6(const HeadParams& p, hipStream_t stream) {
+    if (p.Ctp & 31) return (int)hipErrorInvalidValue;
+    const int m3 = p.K <= 16 ? 1 : 2;
+    if (p.C3p < 16 * m3 || (p.C3p & 15)) return (int)hipErrorInvalidValue;
+    if (p.C0p == 32 && m3 == 1) return launch_head_x6_t<1, 1>(p, stream);
+    if (p.C0p == 32 && m3 == 2) return launch_head_x6_t<1, 2>(p, stream);
+    if (p.C0p == 64 && m3 == 1) return launch_head_x6_t<2, 1>(p, stream);
+    if (p.C0p == 64 && m3 == 2) return launch_head_x6_t<2, 2>(p, stream);
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace esa

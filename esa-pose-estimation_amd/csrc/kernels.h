@@ -178,6 +178,11 @@ bool head_fused_bf_supported(int H, int W, const int th[3], const int tw[3], int
 size_t head_w3_bf_bytes(int K, int Ctp);
 void pack_head_w3_bf(const float* w, int K, int Ct, int Ctp, void* dst);
 
+// fp32-grade mode (head_x6.hip): x0, t[b] and y are f32 NHWC tensors; w0 / w3 = pack_conv_weights_x6(k = 1) of the branch-0
+// slice of last_layer[0] and of last_layer[3] (cout padded to 16 or 32)
+int launch_head_x6(const HeadParams& p, hipStream_t stream);
+bool head_x6_supported(int H, int W, const int th[3], const int tw[3], int C0p, int K);
+
 // ---- second-generation fused head: bilinear up-sampling on the matrix cores (head_t.hip, head_fused2.hip)
 constexpr int HT_PAD = 1;       // T layout: stored column = x + HT_PAD
 struct HeadTParams {

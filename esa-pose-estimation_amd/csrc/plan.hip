@@ -856,8 +856,10 @@ int build_plan_ops(esahrnet_ctx& c) {
         // bf16 mode: the slices t_1..t_3 are shared by two alternatives, chosen per input shape (plan_shape):
         // alt 2 = head_fused_bf.hip (W0, interpolation, ReLU, last_layer[3] in one kernel) where its source-region
         // geometry holds, alt 1 = slice 0 + fuse + 1x1 (the 720-channel tensors materialised) otherwise
-        const bool bf_head = c.bf && ys.size() == 4 && (c.padc(pre[0]) == 64 || c.padc(pre[0]) == 128) &&
-                             !getenv("ESAHRNET_BF_UNFUSED_HEAD");
+        // (fp32-grade mode: the same arrangement with head_x6.hip; f32 NHWC slices, ESAHRNET_X6_UNFUSED_HEAD=1 keeps alt 1)
+        const bool bf_head = ys.size() == 4 &&
+                             ((c.bf && (c.padc(pre[0]) == 64 || c.padc(pre[0]) == 128) && !getenv("ESAHRNET_BF_UNFUSED_HEAD")) ||
+                              (c.x6() && (c.padc(pre[0]) == 32 || c.padc(pre[0]) == 64) && !getenv("ESAHRNET_X6_UNFUSED_HEAD")));
         std::vector<int> hterms(ys.size(), -1);
         int off = 0;
         std::vector<int> offs;
@@ -936,6 +938,10 @@ bool head2_for_shape(const esahrnet_ctx& c, const std::vector<int>& lh, const st
         th[i] = lh[lv]; tw[i] = lw[lv];
     }
     const Tensor& t0 = c.tensors[o.in];
+    if (o.kind == OP_HEADBF && c.x6()) {
+        if (ulo) *ulo = false;
+        return esa::head_x6_supported(lh[t0.level], lw[t0.level], th, tw, t0.Cp, c.cfg.num_keypoints);
+    }
     if (o.kind == OP_HEADBF) {
         if (ulo) *ulo = false;
         return esa::head_fused_bf_supported(lh[t0.level], lw[t0.level], th, tw, t0.Cp, c.cfg.num_keypoints);
@@ -1363,6 +1369,14 @@ int esahrnet_commit(esahrnet_handle h) {
             packed.assign(esa::head_w3_bf_bytes(s3.cout, ctp), 0);
             esa::pack_head_w3_bf(s3.w.data(), s3.cout, ct, ctp, packed.data());
             if (upload(packed, &h->head_w3)) return 1;
+        } else if (h->x6()) {      // head_x6.hip: both in conv_x6's three-term fragments (its K order is the h0 fragment's)
+            packed.assign(esa::packed_weight_bytes_x6(ctp, c0p, 1), 0);
+            esa::pack_conv_weights_x6(w.data(), ct, c0, 1, ctp, c0p, packed.data());
+            if (upload(packed, &h->head_w0)) return 1;
+            const int m3p = s3.cout <= 16 ? 16 : 32;
+            packed.assign(esa::packed_weight_bytes_x6(m3p, ctp, 1), 0);
+            esa::pack_conv_weights_x6(s3.w.data(), s3.cout, ct, 1, m3p, ctp, packed.data());
+            if (upload(packed, &h->head_w3)) return 1;
         } else {
             packed.assign(esa::packed_weight_bytes(ctp, c0p, 1), 0);
             esa::pack_conv_weights(w.data(), ct, c0, 1, ctp, c0p, packed.data());
@@ -1700,7 +1714,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                     p.Ctp = tt.Cp;
                 }
                 p.C0p = ti.Cp; p.C3p = to.Cp; p.K = h->cfg.num_keypoints;
-                rc = esa::launch_head_bf(p, stream);
+                rc = h->x6() ? esa::launch_head_x6(p, stream) : esa::launch_head_bf(p, stream);
                 break;
             }
             case OP_HEADT: {
@@ -1930,7 +1944,7 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             const ConvSpec& s0 = h->specs[h->spec_l0];
             const ConvSpec& s3 = h->specs[h->spec_l3];
             const Tensor& to = h->tensors[o.out];
-            snprintf(out->kernel, sizeof out->kernel, "head_fused_bf");
+            snprintf(out->kernel, sizeof out->kernel, h->x6() ? "head_x6" : "head_fused_bf");
             snprintf(out->label, sizeof out->label, "last_layer.0[:, 0:%d] + up + last_layer.3", h->head_c0);
             out->flops = 2.0 * n * lh[to.level] * lw[to.level] * ((double)s0.cout * h->head_c0 + (double)s3.cout * s3.cin);
             out->bytes = tbytes(o.in) + tbytes(o.out);
