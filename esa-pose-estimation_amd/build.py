@@ -11,6 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libesahrnet.so")
 SOURCES = ["conv_mfma.hip", "conv_s2c32.hip", "conv_x6.hip", "conv1x1.hip", "stem.hip", "stem_fused.hip", "bblock32.hip", "cbam.hip", "crops.hip", "fuse.hip", "head.hip", "head_fused.hip", "head_fused2.hip", "head_fused_bf.hip", "head_gather.hip", "head_t.hip", "head_x6.hip", "keypoints.hip", "layout.hip", "plan.hip", "pnp_host.hip"]
+# conv_x6.hip: MFMA results that a VALU instruction reads next (the per-row fresh sums) are allocated in VGPRs — with
+# AGPR destinations hipcc copies them out right behind the chain's last MFMA and pads the hazard with s_nop (csrc/conv_x6.hip)
+PER_FILE_FLAGS = {"conv_x6.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 HEADERS = ["kernels.h", "sb.h", "conv_cfg.h", "devstate.h", os.path.join("..", "..", "include", "esahrnet.h")]
 
 
@@ -41,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for s in SOURCES:
         o = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [_hipcc(), *flags, *PER_FILE_FLAGS.get(s, []), "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

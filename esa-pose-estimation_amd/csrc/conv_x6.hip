@@ -31,12 +31,30 @@
 // so MFMA K index (k-group sg, element j) is channel  j < 4 ? 4sg + j : 16 + 4sg + (j - 4);  the packed weights use
 // the same permutation (x6_chan_of_k).
 #include <algorithm>
+#include <cstdio>
 #include <type_traits>
 
 #include "conv_cfg.h"
 #include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
+
+#ifdef X6_TRACE
+// debug build only (tools/trace_x6.py, -DX6_TRACE=1): shader-clock stamps of the first workgroups' wave 0, 8 events x 32 steps
+__device__ unsigned long long g_x6_trace[64 * 32 * 8];
+extern "C" int esa_debug_x6_trace(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_x6_trace), sizeof(g_x6_trace)); }
+__device__ unsigned long long g_x6_wg[1024 * 4];      // per workgroup: wall clock (100 MHz) at start / end, steps, HW_ID
+extern "C" int esa_debug_x6_wg(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_x6_wg), sizeof(g_x6_wg)); }
+#endif
+
+// timing experiments only (tools/trace_x6.py): bit mask of parts compiled OUT — 1 tile global loads, 2 split + LDS writes,
+// 4 weight reloads, 8 LDS operand reads, 16 residual loads + output stores, 32 barrier.  0 in the product build.
+#ifndef X6_ABL
+#define X6_ABL 0
+#endif
+#ifndef X6_PRIO_FLIP
+#define X6_PRIO_FLIP 1
+#endif
 
 namespace esa {
 
@@ -99,9 +117,32 @@ __device__ __forceinline__ void x6_split_pair(float a, float b, uint32_t& h, uin
     l = __builtin_bit_cast(uint32_t, __builtin_convertvector(s, bf16x2));
 }
 
-template <int KS, int S, int CT, int NR>
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void x6_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        x6_static_for<B + 1, E>(f);
+    }
+}
+// staging units of a phase's row r: the last XH rows take one unit each (phases shorter than XH rows several in row 0);
+// unit u of the half goes to row max(0, NR - XH + u)
+__host__ __device__ constexpr int x6_unit_row(int NR, int XH, int u) { return NR - XH + u > 0 ? NR - XH + u : 0; }
+__host__ __device__ constexpr int x6_units_in_row(int NR, int XH, int nunits, int r) {
+    int n = 0;
+    for (int u = 0; u < nunits; ++u) n += x6_unit_row(NR, XH, u) == r ? 1 : 0;
+    return n;
+}
+__host__ __device__ constexpr int x6_first_unit_in_row(int NR, int XH, int nunits, int r) {
+    for (int u = 0; u < nunits; ++u)
+        if (x6_unit_row(NR, XH, u) == r) return u;
+    return 0;
+}
+
+template <int KS, int S, int CT, int NR, int NW>
 struct X6Cfg {
-    static constexpr int RG = 4 / CT;                       // row groups
+    static constexpr int NT = NW * 64;                      // threads per workgroup (NW waves: 4 = one per SIMD, 8 = two)
+    static constexpr int RG = NW / CT;                      // row groups
     static constexpr int TH = RG * NR;                      // output rows per workgroup tile
     static constexpr int PAD = (KS - 1) / 2;
     static constexpr int TAPS = KS * KS;
@@ -111,7 +152,7 @@ struct X6Cfg {
     static constexpr int PLANE = ((NPIX * 16 + 128 + 255) / 256) * 256;
     static constexpr int XBYTES = 12 * PLANE;               // one tile buffer: 4 k-groups x 3 terms
     static constexpr int LDS = 2 * XBYTES;
-    static constexpr int XITER = (NPIX * 4 + NTHREADS - 1) / NTHREADS;
+    static constexpr int XITER = (NPIX * 4 + NT - 1) / NT;
     static constexpr int ROWS = (NR - 1) * S + KS;          // input rows a wave touches
     // B-operand reads (ds_read_b128: lane groups pair k-groups {0,1} and {2,3}, one term per instruction) want the
     // planes of a k-group pair congruent mod 256 B at stride 1 and one 16-byte slot apart at stride 2 (conv_cfg.h)
@@ -135,9 +176,10 @@ struct X6Pos {            // one (item, chunk) step of the workgroup's stream
     bool ok;
 };
 
-template <int KS, int S, int CT, int NR>
+template <int KS, int S, int CT, int NR, int NW>
 __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, const int bid, const int G) {
-    using C = X6Cfg<KS, S, CT, NR>;
+    using C = X6Cfg<KS, S, CT, NR, NW>;
+    constexpr int QSTEP = C::NT / 4;            // tile pixels staged per iteration
     constexpr int TAPS = C::TAPS, ROWS = C::ROWS, XITER = C::XITER;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -173,12 +215,12 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         return q;
     };
 
-    // ---- staging map: thread -> (k-group sg, tile pixel q0 + 64*it), fixed for the launch ----
+    // ---- staging map: thread -> (k-group sg, tile pixel q0 + QSTEP*it), fixed for the launch ----
     const int sg = tid & 3, q0 = tid >> 2;
     int qyx[XITER];                             // tile-local (row << 8 | column), -1 beyond the tile
 #pragma unroll
     for (int it = 0; it < XITER; ++it) {
-        const int q = q0 + it * 64;
+        const int q = q0 + it * QSTEP;
         const int qy = q / C::IW, qx = q - qy * C::IW;
         qyx[it] = q < C::NPIX ? (qy << 8 | qx) : -1;
     }
@@ -196,16 +238,17 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
             const bool inside = qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             const uint32_t off = inside ? (uint32_t)((gy * p.W + gx) * pixb + sg * 16) : X6_OOB;
-            xr[it - i0][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so, 0);
-            xr[it - i0][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so + 64, 0);
+            if (!(X6_ABL & 1)) {
+                xr[it - i0][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so, 0);
+                xr[it - i0][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so + 64, 0);
+            }
         }
     };
     char* const xwr = smem + q0 * 16 + sg * (3 * C::PLANE) + (S == 2 ? (sg & 1) * 16 : 0);      // plane_off(sg, 0) + pixel slot
-    auto write_tile = [&](int buf, auto half_c) __attribute__((always_inline)) {
-        constexpr int i0 = decltype(half_c)::value * XH;
-#pragma unroll
-        for (int it = i0; it < i0 + XH && it < XITER; ++it) {
-            if (q0 + it * 64 >= C::NPIX) continue;
+    // unit `it` of the half in flight: split into three exact bf16 terms, three 16-byte LDS writes
+    auto write_unit = [&](int buf, int i0, int it) __attribute__((always_inline)) {
+        {
+            if (it >= XITER || (X6_ABL & 2)) return;
             u32x4 t0, t1, t2;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -215,10 +258,12 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                     x6_split_pair(__uint_as_float(xr[it - i0][h][2 * k]), __uint_as_float(xr[it - i0][h][2 * k + 1]), a, b, c);
                     t0[2 * h + k] = a; t1[2 * h + k] = b; t2[2 * h + k] = c;
                 }
-            char* o = xwr + buf * C::XBYTES + it * 1024;
-            *reinterpret_cast<u32x4*>(o) = t0;
-            *reinterpret_cast<u32x4*>(o + C::PLANE) = t1;
-            *reinterpret_cast<u32x4*>(o + 2 * C::PLANE) = t2;
+            char* o = xwr + buf * C::XBYTES + it * (QSTEP * 16);
+            if ((it + 1) * QSTEP <= C::NPIX || q0 + it * QSTEP < C::NPIX) {       // (only the tile's last unit is partial)
+                *reinterpret_cast<u32x4*>(o) = t0;
+                *reinterpret_cast<u32x4*>(o + C::PLANE) = t1;
+                *reinterpret_cast<u32x4*>(o + 2 * C::PLANE) = t2;
+            }
         }
     };
 
@@ -226,6 +271,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     bf16x8 wf[TAPS][3];
     auto load_w = [&](int ct, int ch, int kx) __attribute__((always_inline)) {
         const uint4* ws = p.w + ((size_t)((ct * CT + cw) * nchunks + ch) * TAPS) * 3 * 64 + lane;
+        if (X6_ABL & 4) return;
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
@@ -240,6 +286,11 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     decode(cur);
     constexpr auto H0 = std::integral_constant<int, 0>{};
     constexpr auto H1 = std::integral_constant<int, 1>{};
+    auto write_tile = [&](int buf, auto half_c) __attribute__((always_inline)) {
+        constexpr int i0 = decltype(half_c)::value * XH;
+#pragma unroll
+        for (int it = i0; it < i0 + XH; ++it) write_unit(buf, i0, it);
+    };
     load_tile(cur, H0);
     write_tile(0, H0);
     if constexpr (XH < XITER) {
@@ -251,23 +302,60 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) load_w(cur.ct, 0, kx);
     f32x4 bv = load_bias(cur.ct);
+    asm volatile("" : "+v"(bv));                // (waited for here, once: at the loop head hipcc would otherwise merge "bias pending
+                                                // behind 27 weight loads" into every iteration's state and drain vmcnt(0) there)
 
     const char* const xrd0 = smem + ((rg * NR * S) * C::IW + px * S) * 16 + C::plane_off(0, 0) + g * (3 * C::PLANE) +
                              (S == 2 ? (g & 1) * 16 : 0);
     f32x4 acc[NR];
     int buf = 0;
+    int pstep = 0;
+#ifdef X6_TRACE
+    int tstep = 0;
+    const bool ton = KS == 3 && S == 1 && bid < 64 && tid == 0;
+    const bool wgon = KS == 3 && S == 1 && bid < 1024 && tid == 0;
+    if (wgon) {
+        g_x6_wg[bid * 4] = __builtin_amdgcn_s_memrealtime();
+        g_x6_wg[bid * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#define X6_TR(EV) if (ton && tstep < 32) g_x6_trace[(bid * 32 + tstep) * 8 + (EV)] = __builtin_amdgcn_s_memtime();
+#else
+#define X6_TR(EV)
+#endif
     while (true) {
-        __syncthreads();        // tile of this step published; every wave is done reading the other buffer
+        // Two workgroups share a CU (X6_MODE 2): the hardware arbitrates the matrix pipe by priority, then AGE — left alone
+        // the older workgroup runs at full speed, the younger one on the leftovers, and finishes its equal share of the items
+        // alone on a half-empty CU.  The priority alternates per step between the grid's halves (workgroups b and b + G/2
+        // usually share a CU), so both progress at the same average rate.
+        if (X6_PRIO_FLIP) {
+            if (((pstep++) ^ (bid * 2 >= G ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        X6_TR(0)
+#ifdef X6_TRACE
+        if (ton && tstep < 32) g_x6_trace[(bid * 32 + tstep) * 8 + 7] = __builtin_amdgcn_s_memrealtime();      // 100 MHz wall clock
+#endif
+        if (!(X6_ABL & 32)) __syncthreads();        // tile of this step published; every wave is done reading the other buffer
+        X6_TR(1)
         const bool last_chunk = cur.c + 1 == nchunks;
-        const bool reload = nxt.ok && (nchunks > 1 || nxt.ct != cur.ct);
+        // Every load of the loop is UNCONDITIONAL (the next step's weight thirds even when they are the ones already held or
+        // no step follows, the residual rows and the output stores of a step that does not end its item with out-of-range
+        // offsets: an issue slot, no traffic): with a load behind a run-time branch hipcc cannot count what is in flight at
+        // the join and drains vmcnt(0) there — measured, a phase then started 1-2 k cycles late behind the L2 latency of the
+        // weight third issued just before it.
+        const int wct = nxt.ok ? nxt.ct : cur.ct, wch = nxt.ok ? nxt.c : cur.c;
         if (cur.c == 0) {
 #pragma unroll
             for (int t = 0; t < NR; ++t) acc[t] = bv;
         }
+        // bias of the next step's cout slice: the OLDEST load of the step, so that the wait in front of the next item's
+        // accumulator start leaves the weight thirds issued behind it in flight
+        f32x4 bvn = load_bias(wct);
+        __builtin_amdgcn_sched_barrier(0);
         // output addressing of this wave's rows; the residual rows (last chunk) are loaded a few rows ahead of their use
         const int co0 = (cur.ct * CT + cw) * 16 + g * 4;
         const int rox = cur.ox0 + px, roy = cur.oy0 + rg * NR;
-        const uint32_t o0 = rox < p.OW ? (uint32_t)((roy * p.OW + rox) * opix + co0 * 4) : X6_OOB;
+        const uint32_t o0 = (rox < p.OW && last_chunk) ? (uint32_t)((roy * p.OW + rox) * opix + co0 * 4) : X6_OOB;
         const int orow = p.OW * opix;
         const int nrows = p.OH - roy;
         const bool do_res = p.res != nullptr;
@@ -280,16 +368,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         // condition makes hipcc drain vmcnt(0) at the join)
         auto res_load = [&](int t) __attribute__((always_inline)) {
             const uint32_t ro = t < nrows ? o0 + (uint32_t)(t * orow) : X6_OOB;
-            rc[t % RCN] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ro, 0, 0);
-        };
-        auto epilogue_row = [&](int t) __attribute__((always_inline)) {
-            u32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(relu_opt(acc[t][k] + __uint_as_float(rc[t % RCN][k]), rfl));
-            const uint32_t so = t < nrows ? o0 + (uint32_t)(t * orow) : X6_OOB;
-            // (image base in the descriptor, scalar offset the constant 0: see the store-data hazard note in
-            // conv_s2c32.hip — hipcc pads 16-byte buffer stores only when they carry no SGPR soffset)
-            __builtin_amdgcn_raw_buffer_store_b128(o, ry, (int)so, 0, 0);
+            if (!(X6_ABL & 16)) rc[t % RCN] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)ro, 0, 0);
         };
         const char* const xrd = xrd0 + buf * C::XBYTES;
         // One kx phase.  Accumulation order (tools/ubench/x6_numerics.hip: 7x less rounding error than one long chain, better
@@ -297,85 +376,121 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         // FRESH accumulator — the fifteen low-order products first, while the sum is small, the three a0*b0 products last —
         // and added to the item's running sum by one VALU add, one row late (the chain's result is not waited for).
         // The B fragments of KS input rows stay in registers: every LDS read feeds the taps of up to three output rows.
-        f32x4 tq[2];
-        auto phase = [&](auto kx_c, auto epi_c) __attribute__((always_inline)) {
+        // `wh`: half of the next step's tile (in registers since the start of this phase) that is split and written to the
+        // other LDS buffer during the LAST rows of this phase, one unit per row, in the issue shadow of the row's MFMAs
+        // (-1: none).  LDS operand reads run one output row ahead of the MFMAs that consume them, pinned by a
+        // sched_barrier: left alone, hipcc sinks each ds_read next to its first use and waits for it.
+        auto phase = [&](auto kx_c, auto epi_c, auto wh_c) __attribute__((always_inline)) {
             constexpr int kx = decltype(kx_c)::value;
             constexpr bool EPI = decltype(epi_c)::value;         // last phase of the item: rows leave as they complete
-            bf16x8 xw[KS][3];
+            constexpr int WH = decltype(wh_c)::value;
+            constexpr int RING = KS + S;                         // input rows of output rows r and r + 1
+            constexpr int NSLOT = 6 * KS;                        // MFMAs of a row
+            bf16x8 xw[RING][3];
+            auto read_rows = [&](int lo, int hi) __attribute__((always_inline)) {
+                if ((X6_ABL & 8) && lo > 0) return;
+#pragma unroll
+                for (int j = lo; j <= hi; ++j)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        xw[j % RING][t] = *reinterpret_cast<const bf16x8*>(xrd + (j * C::IW + kx) * 16 + t * C::PLANE);
+            };
+            read_rows(0, KS - 1);
             if (EPI) {
 #pragma unroll
                 for (int t = 0; t < RCN - 1 && t < NR; ++t) res_load(t);
             }
-#pragma unroll
-            for (int r = 0; r <= NR; ++r) {
-                if (r < NR) {
-                    const int lo = r == 0 ? 0 : (r - 1) * S + KS, hi = r * S + KS - 1;      // input rows not yet in the window
-#pragma unroll
-                    for (int j = lo; j <= hi; ++j)
-#pragma unroll
-                        for (int t = 0; t < 3; ++t)
-                            xw[j % KS][t] = *reinterpret_cast<const bf16x8*>(xrd + (j * C::IW + kx) * 16 + t * C::PLANE);
-                    f32x4 sm = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ky = 0; ky < KS; ++ky) {
-                        const int tp = ky * KS + kx, w = (r * S + ky) % KS;
-                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][2], xw[w][0], sm, 0, 0, 0);
-                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][0], xw[w][2], sm, 0, 0, 0);
-                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][1], xw[w][1], sm, 0, 0, 0);
-                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][1], xw[w][0], sm, 0, 0, 0);
-                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][0], xw[w][1], sm, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int ky = 0; ky < KS; ++ky) {
-                        const int tp = ky * KS + kx, w = (r * S + ky) % KS;
-                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][0], xw[w][0], sm, 0, 0, 0);
-                    }
-                    tq[r & 1] = sm;
+            f32x4 sm = {0.f, 0.f, 0.f, 0.f}, tprev = {0.f, 0.f, 0.f, 0.f};
+            constexpr int NUNITS = WH < 0 ? 0 : (XITER - WH * XH < XH ? XITER - WH * XH : XH);      // units of this phase's half
+            x6_static_for<0, NR + 1>([&](auto r_c) __attribute__((always_inline)) {
+                constexpr int r = decltype(r_c)::value;
+                // One scheduling region per output row: its MFMAs, the LDS reads of the rows that output row r + 1 adds to the
+                // window, the running-sum add and epilogue of row r - 1, the split + LDS writes of this row's staging units.
+                // (The wave issues in order and hipcc puts everything else behind the row's MFMAs; what fills the matrix pipe
+                // meanwhile is the SIMD's other wave.)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (r + 1 < NR) read_rows(r * S + KS, (r + 1) * S + KS - 1);
+                if constexpr (r < NR) {
+                    sm = f32x4{0.f, 0.f, 0.f, 0.f};
+                    x6_static_for<0, NSLOT>([&](auto i_c) __attribute__((always_inline)) {
+                        constexpr int i = decltype(i_c)::value;
+                        // chain order: the five low-order products of every tap first, the KS a0*b0 products last
+                        constexpr int ky = i < 5 * KS ? i / 5 : i - 5 * KS, pr = i < 5 * KS ? i % 5 : 5;
+                        constexpr int tp = ky * KS + kx, w = (r * S + ky) % RING;
+                        constexpr int wa = pr == 0 ? 2 : (pr == 2 || pr == 3) ? 1 : 0, xb = pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][wa], xw[w][xb], sm, 0, 0, 0);
+                    });
                 }
-                if (r > 0) {
-                    acc[r - 1] += tq[(r - 1) & 1];
-                    if (EPI) epilogue_row(r - 1);
+                if constexpr (r > 0) {
+                    acc[r - 1] += tprev;
+                    // (pinned: LLVM otherwise sinks these adds to the end of the step — sixteen fresh sums per phase parked in
+                    // registers, then bursts of adds)
+                    asm volatile("" : "+v"(acc[r - 1]));
+                    if constexpr (EPI) {          // row r - 1 leaves
+                        u32x4 eo;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) eo[k] = __float_as_uint(relu_opt(acc[r - 1][k] + __uint_as_float(rc[(r - 1) % RCN][k]), rfl));
+                        const uint32_t so = (r - 1) < nrows ? o0 + (uint32_t)((r - 1) * orow) : X6_OOB;
+                        // (image base in the descriptor, scalar offset the constant 0: see the store-data hazard note in
+                        // conv_s2c32.hip — hipcc pads 16-byte buffer stores only when they carry no SGPR soffset)
+                        if (!(X6_ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(eo, ry, (int)so, 0, 0);
+                        else asm volatile("" :: "v"(eo));
+                    }
                 }
-                if (EPI && r + RCN - 1 < NR) res_load(r + RCN - 1);      // into the slot the epilogue above has just read
-            }
+                if constexpr (EPI && r + RCN - 1 < NR) res_load(r + RCN - 1);      // into the slot the epilogue above has just read
+                // staging units of this row: the last XH rows take one each (short phases several)
+                if constexpr (r < NR) {
+                    constexpr int ucount = x6_units_in_row(NR, XH, NUNITS, r), ufirst = x6_first_unit_in_row(NR, XH, NUNITS, r);
+                    x6_static_for<0, ucount>([&](auto u_c) __attribute__((always_inline)) {
+                        write_unit(buf ^ 1, WH * XH, WH * XH + ufirst + decltype(u_c)::value);
+                    });
+                }
+                tprev = sm;
+            });
+            __builtin_amdgcn_sched_barrier(0);
         };
         constexpr auto F = std::false_type{};
         constexpr auto T = std::true_type{};
+        constexpr auto W0 = std::integral_constant<int, 0>{};
+        constexpr auto W1 = std::integral_constant<int, XH < XITER ? 1 : -1>{};
+        constexpr auto WN = std::integral_constant<int, -1>{};
         if constexpr (KS == 3) {
-            // (the sched_barriers keep hipcc from hoisting the next step's loads into the phase before: the registers they
-            // fill are the ones that phase is still reading — hoisted, every third and the tile would need a second set)
-            // the other buffer is free since the barrier: the tile of step s+1 goes there, half by half
+            // The tile of step s+1 goes to the other buffer (free since the barrier) half by half: loads at the start of phases
+            // 0 / 1, split + LDS writes in those phases' last rows.  The weight third a phase has used is refilled for step
+            // s+1 right behind it.  (The sched_barriers keep hipcc from hoisting those loads into the phase before: the
+            // registers they fill are the ones that phase is still reading.)
             load_tile(nxt, H0);
             __builtin_amdgcn_sched_barrier(0);
-            phase(std::integral_constant<int, 0>{}, F);
-            __builtin_amdgcn_sched_barrier(0);
-            write_tile(buf ^ 1, H0);
-            __builtin_amdgcn_sched_barrier(0);
+            X6_TR(2)
+            phase(std::integral_constant<int, 0>{}, F, W0);
+            asm volatile("" : "+v"(bvn));       // the bias load is complete here (older than the tile half just consumed): waited
+                                                // for now, with a counted vmcnt, not at the next step's start behind the weight loads
+            X6_TR(3)
             if constexpr (XH < XITER) load_tile(nxt, H1);
-            if (reload) load_w(nxt.ct, nxt.c, 0);
+            load_w(wct, wch, 0);
             __builtin_amdgcn_sched_barrier(0);
-            phase(std::integral_constant<int, 1>{}, F);
+            phase(std::integral_constant<int, 1>{}, F, W1);
+            X6_TR(4)
+            load_w(wct, wch, 1);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (XH < XITER) write_tile(buf ^ 1, H1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (reload) load_w(nxt.ct, nxt.c, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (last_chunk) phase(std::integral_constant<int, 2>{}, T);
-            else phase(std::integral_constant<int, 2>{}, F);
-            __builtin_amdgcn_sched_barrier(0);
-            if (reload) load_w(nxt.ct, nxt.c, 2);
+            phase(std::integral_constant<int, 2>{}, T, WN);
+            X6_TR(5)
+            load_w(wct, wch, 2);
         } else {
             load_tile(nxt, H0);
             __builtin_amdgcn_sched_barrier(0);
-            if (last_chunk) phase(std::integral_constant<int, 0>{}, T);
-            else phase(std::integral_constant<int, 0>{}, F);
-            __builtin_amdgcn_sched_barrier(0);
-            write_tile(buf ^ 1, H0);
-            if (reload) load_w(nxt.ct, nxt.c, 0);
+            phase(std::integral_constant<int, 0>{}, T, W0);
+            asm volatile("" : "+v"(bvn));
+            load_w(wct, wch, 0);
         }
-        if (last_chunk) {
-            if (nxt.ok && nxt.ct != cur.ct) bv = load_bias(nxt.ct);
-        }
+        bv = bvn;
+        X6_TR(6)
+#ifdef X6_TRACE
+        ++tstep;
+#endif
+#ifdef X6_TRACE
+        if (wgon && !nxt.ok) { g_x6_wg[bid * 4 + 1] = __builtin_amdgcn_s_memrealtime(); g_x6_wg[bid * 4 + 2] = tstep; }
+#endif
         if (!nxt.ok) break;
         cur = nxt;
         nxt = advance(cur);
@@ -383,16 +498,18 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     }
 }
 
-template <int KS, int S, int CT, int NR>
-__global__ __launch_bounds__(NTHREADS, 1) void conv_x6_kernel(ConvParams p, X6Geo geo) {
-    x6_body<KS, S, CT, NR>(p, geo, (int)blockIdx.x, (int)gridDim.x);
+// OCC: workgroups per CU the register / LDS budget is cut for
+template <int KS, int S, int CT, int NR, int NW, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC * NW / 4) void conv_x6_kernel(ConvParams p, X6Geo geo) {
+    static_assert(OCC * X6Cfg<KS, S, CT, NR, NW>::LDS <= 160 * 1024, "tile buffers of OCC workgroups exceed the CU's LDS");
+    x6_body<KS, S, CT, NR, NW>(p, geo, (int)blockIdx.x, (int)gridDim.x);
 }
 
 uint32_t x6_magic(int d) { return (uint32_t)(0xffffffffull / (uint64_t)d); }
 
-template <int KS, int S, int CT, int NR>
+template <int KS, int S, int CT, int NR, int NW, int OCC>
 int launch_x6_t(const ConvParams& p, hipStream_t stream) {
-    using C = X6Cfg<KS, S, CT, NR>;
+    using C = X6Cfg<KS, S, CT, NR, NW>;
     X6Geo geo;
     geo.tiles_x = (p.OW + TW - 1) / TW;
     geo.tiles_y = (p.OH + C::TH - 1) / C::TH;
@@ -403,12 +520,12 @@ int launch_x6_t(const ConvParams& p, hipStream_t stream) {
     geo.m_ct = x6_magic(geo.ctiles);
     geo.m_tx = x6_magic(geo.tiles_x);
     geo.m_ty = x6_magic(geo.tiles_y);
-    const int cus = device_cus();
+    const int cus = OCC * device_cus();
     int grid = (int)(nitems < cus ? nitems : cus);
     if (grid > geo.ctiles) grid -= grid % geo.ctiles;   // grid stride keeps the cout slice of a workgroup constant
-    auto kern = conv_x6_kernel<KS, S, CT, NR>;
+    auto kern = conv_x6_kernel<KS, S, CT, NR, NW, OCC>;
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), C::LDS)) return e_;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), C::LDS, stream, p, geo);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), C::LDS, stream, p, geo);
     return (int)hipGetLastError();
 }
 
@@ -437,31 +554,60 @@ static int x6_variant(const ConvParams& p, int k, int stride) {
     return 4;
 }
 
+// X6_MODE — how a CU is filled (measured on MI355X, 64 -> 64 channels 64x64, batch 128, cycles per step of 864 MFMAs per
+// SIMD; 13.8 k = matrix pipe never idle):
+//   0: ONE workgroup of 4 waves (one per SIMD, 512 registers, 16-row tile)                      20.6 k
+//   1: ONE workgroup of 8 waves (two per SIMD, 16-row tile)                                     19.0 k — the SIMD partners meet at
+//      the SAME barrier every step: the older wave wins the matrix pipe, finishes its step and waits 4.2 k cycles for the
+//      younger one, which then runs alone; with the barrier compiled out (wrong results) the same code takes 14.8 k
+//   2: TWO workgroups of 4 waves (8-row tiles): SIMD partners belong to different workgroups and never wait for each other;
+//      a workgroup's own four waves sit on four SIMDs, do the same work and reach their barrier together
+#ifndef X6_MODE
+#define X6_MODE 2
+#endif
+#if X6_MODE == 1
+#define X6_KARGS(KS_, S_, CT_, NR1_) KS_, S_, CT_, (NR1_) / 2, 8, 1
+#elif X6_MODE == 2
+#define X6_KARGS(KS_, S_, CT_, NR1_) KS_, S_, CT_, ((S_) == 2 ? (NR1_) / 2 : ((NR1_) > 8 ? 8 : (NR1_) == 8 && (CT_) == 2 ? 4 : (NR1_))), 4, 2
+#else
+#define X6_KARGS(KS_, S_, CT_, NR1_) KS_, S_, CT_, NR1_, 4, 1
+#endif
 int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream) {
     if (!conv_x6_supported(p, k, stride)) return (int)hipErrorInvalidValue;
     const int v = x6_variant(p, k, stride);
     if (k == 3) {
         switch (v) {
-            case 0: return launch_x6_t<3, 2, 4, 4>(p, stream);
-            case 1: return launch_x6_t<3, 2, 2, 2>(p, stream);
-            case 2: return launch_x6_t<3, 1, 4, 8>(p, stream);
-            case 3: return launch_x6_t<3, 1, 4, 16>(p, stream);
-            default: return launch_x6_t<3, 1, 2, 8>(p, stream);
+            case 0: return launch_x6_t<X6_KARGS(3, 2, 4, 4)>(p, stream);
+            case 1: return launch_x6_t<X6_KARGS(3, 2, 2, 2)>(p, stream);
+            case 2: return launch_x6_t<X6_KARGS(3, 1, 4, 8)>(p, stream);
+            case 3: return launch_x6_t<X6_KARGS(3, 1, 4, 16)>(p, stream);
+            default: return launch_x6_t<X6_KARGS(3, 1, 2, 8)>(p, stream);
         }
     }
     switch (v) {
-        case 2: return launch_x6_t<1, 1, 4, 8>(p, stream);
-        case 3: return launch_x6_t<1, 1, 4, 16>(p, stream);
-        default: return launch_x6_t<1, 1, 2, 8>(p, stream);
+        case 2: return launch_x6_t<X6_KARGS(1, 1, 4, 8)>(p, stream);
+        case 3: return launch_x6_t<X6_KARGS(1, 1, 4, 16)>(p, stream);
+        default: return launch_x6_t<X6_KARGS(1, 1, 2, 8)>(p, stream);
     }
 }
 
+#define X6_STR2(...) #__VA_ARGS__
+#define X6_STR(...) X6_STR2(__VA_ARGS__)
 const char* conv_x6_kernel_name(const ConvParams& p, int k, int stride) {
-    static const char* n3[] = {"conv_x6_kernel<3, 2, 4, 4>", "conv_x6_kernel<3, 2, 2, 2>", "conv_x6_kernel<3, 1, 4, 8>",
-                               "conv_x6_kernel<3, 1, 4, 16>", "conv_x6_kernel<3, 1, 2, 8>"};
-    static const char* n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 8>", "conv_x6_kernel<1, 1, 4, 16>", "conv_x6_kernel<1, 1, 2, 8>"};
-    const int v = x6_variant(p, k, stride);
-    return k == 3 ? n3[v] : n1[v];
+    // (as rocprofv3 prints the instantiation: the evaluated template arguments)
+    static char names[2][5][48];
+    static bool init = false;
+    if (!init) {
+        const int nr1[5] = {4, 2, 8, 16, 8}, ct[5] = {4, 2, 4, 4, 2}, st[5] = {2, 2, 1, 1, 1};
+        for (int kk = 0; kk < 2; ++kk)
+            for (int v = 0; v < 5; ++v) {
+                const int KS_ = kk ? 1 : 3, S_ = st[v], CT_ = ct[v], NR1_ = nr1[v];
+                const int a[6] = {X6_KARGS(KS_, S_, CT_, NR1_)};
+                snprintf(names[kk][v], sizeof names[kk][v], "conv_x6_kernel<%d, %d, %d, %d, %d, %d>", a[0], a[1], a[2], a[3], a[4], a[5]);
+            }
+        init = true;
+    }
+    return names[k == 3 ? 0 : 1][x6_variant(p, k, stride)];
 }
 
 }  // namespace esa
