@@ -505,7 +505,84 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void conv_x6_kernel(ConvPara
     x6_body<KS, S, CT, NR, NW>(p, geo, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// Several INDEPENDENT convolutions of one kind (the same-depth 3x3s of an HRModule's branches, the same-depth links of its
+// fuse-down chains, its fuse-up 1x1s: models/seg_hrnet.py:143-220 — none reads another's output) in one launch.
+// Workgroups [start[j], start[j+1]) run convolution j exactly as its own launch would — same items per workgroup, same
+// order, same bits — but the launch gap is paid once and one convolution's tail overlaps the next one's start (at batch 32
+// a branch convolution is only 4 steps per workgroup).  Longest workgroups first.  Both tilings (64 and 32 couts per
+// workgroup) live in the kernel; a workgroup takes the one its convolution needs.  Two workgroups per CU (X6_MODE 2).
+constexpr int X6_MAXJOBS = 6;
+struct X6Jobs {
+    ConvParams p[X6_MAXJOBS];
+    X6Geo geo[X6_MAXJOBS];
+    int start[X6_MAXJOBS + 1];
+    int ct[X6_MAXJOBS];
+    int njobs;
+};
+template <int KS, int S>
+struct X6JobCfg {
+    static constexpr int NR4 = S == 2 ? 2 : 8, NR2 = S == 2 ? 1 : 4;      // rows per wave of the 64- / 32-cout tiling (X6_MODE 2)
+    using C4 = X6Cfg<KS, S, 4, NR4, 4>;
+    using C2 = X6Cfg<KS, S, 2, NR2, 4>;
+    static constexpr int LDS = C4::LDS > C2::LDS ? C4::LDS : C2::LDS;
+};
+template <int KS, int S>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_x6_jobs_kernel(X6Jobs jobs) {
+    const int b = (int)blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < X6_MAXJOBS; ++k) j += (k < jobs.njobs && b >= jobs.start[k]) ? 1 : 0;
+    const int bid = b - jobs.start[j], G = jobs.start[j + 1] - jobs.start[j];
+    if (jobs.ct[j] == 4) x6_body<KS, S, 4, X6JobCfg<KS, S>::NR4, 4>(jobs.p[j], jobs.geo[j], bid, G);
+    else x6_body<KS, S, 2, X6JobCfg<KS, S>::NR2, 4>(jobs.p[j], jobs.geo[j], bid, G);
+}
+
 uint32_t x6_magic(int d) { return (uint32_t)(0xffffffffull / (uint64_t)d); }
+
+template <int KS, int S>
+int launch_x6_jobs_t(const ConvParams* ps, int n, hipStream_t stream) {
+    using J = X6JobCfg<KS, S>;
+    X6Jobs jobs{};
+    const int slots = 2 * device_cus();
+    struct Ord { int idx, grid; long long steps; };
+    Ord order[X6_MAXJOBS];
+    X6Geo geos[X6_MAXJOBS];
+    int cts[X6_MAXJOBS];
+    for (int j = 0; j < n; ++j) {
+        const ConvParams& p = ps[j];
+        X6Geo& geo = geos[j];
+        const int ct = p.Coutp % 64 == 0 ? 4 : 2;
+        const int th = ct == 4 ? J::C4::TH : J::C2::TH;
+        cts[j] = ct;
+        geo.tiles_x = (p.OW + TW - 1) / TW;
+        geo.tiles_y = (p.OH + th - 1) / th;
+        geo.ctiles = p.Coutp / (16 * ct);
+        const long long nitems = (long long)p.N * geo.tiles_y * geo.tiles_x * geo.ctiles;
+        if (nitems <= 0 || nitems > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        geo.nitems = (int)nitems;
+        geo.m_ct = x6_magic(geo.ctiles);
+        geo.m_tx = x6_magic(geo.tiles_x);
+        geo.m_ty = x6_magic(geo.tiles_y);
+        int grid = (int)(nitems < slots ? nitems : slots);
+        if (grid > geo.ctiles) grid -= grid % geo.ctiles;
+        order[j] = {j, grid, ((nitems + grid - 1) / grid) * (p.Cinp >> 5)};
+    }
+    std::sort(order, order + n, [](const Ord& a, const Ord& b) { return a.steps > b.steps; });      // longest workgroups first
+    jobs.njobs = n;
+    int at = 0;
+    for (int k = 0; k < n; ++k) {
+        jobs.p[k] = ps[order[k].idx];
+        jobs.geo[k] = geos[order[k].idx];
+        jobs.ct[k] = cts[order[k].idx];
+        jobs.start[k] = at;
+        at += order[k].grid;
+    }
+    for (int k = n; k <= X6_MAXJOBS; ++k) jobs.start[k] = at;
+    auto kern = conv_x6_jobs_kernel<KS, S>;
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), J::LDS)) return e_;
+    hipLaunchKernelGGL(kern, dim3((unsigned)at), dim3(NTHREADS), J::LDS, stream, jobs);
+    return (int)hipGetLastError();
+}
 
 template <int KS, int S, int CT, int NR, int NW, int OCC>
 int launch_x6_t(const ConvParams& p, hipStream_t stream) {
@@ -593,6 +670,20 @@ int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream) {
 
 #define X6_STR2(...) #__VA_ARGS__
 #define X6_STR(...) X6_STR2(__VA_ARGS__)
+// 2..6 independent convolutions of one kernel size and stride (each one a conv_x6 launch on its own) as ONE launch
+bool conv_x6_jobs_supported(const ConvParams* ps, int n, int k, int stride) {
+    if (X6_MODE != 2 || n < 2 || n > X6_MAXJOBS) return false;
+    for (int j = 0; j < n; ++j)
+        if (!conv_x6_supported(ps[j], k, stride)) return false;
+    return true;
+}
+
+int launch_conv_x6_jobs(const ConvParams* ps, int n, int k, int stride, hipStream_t stream) {
+    if (!conv_x6_jobs_supported(ps, n, k, stride)) return (int)hipErrorInvalidValue;
+    if (k == 1) return launch_x6_jobs_t<1, 1>(ps, n, stream);
+    return stride == 1 ? launch_x6_jobs_t<3, 1>(ps, n, stream) : launch_x6_jobs_t<3, 2>(ps, n, stream);
+}
+
 const char* conv_x6_kernel_name(const ConvParams& p, int k, int stride) {
     // (as rocprofv3 prints the instantiation: the evaluated template arguments)
     static char names[2][5][48];

@@ -75,6 +75,9 @@ void pack_conv_weights_x6(const float* w, int cout, int cin, int k, int coutp, i
 bool conv_x6_supported(const ConvParams& p, int k, int stride);
 int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream);
 const char* conv_x6_kernel_name(const ConvParams& p, int k, int stride);
+// 2..6 independent convolutions of one kernel size and stride on FMT_F32 tensors as ONE launch (conv_x6_jobs_kernel)
+bool conv_x6_jobs_supported(const ConvParams* ps, int n, int k, int stride);
+int launch_conv_x6_jobs(const ConvParams* ps, int n, int k, int stride, hipStream_t stream);
 
 // ---- stem conv1: f32 NCHW -> SB, 3x3 s1, cin in {1..4}, cout = multiple of 32 (stem.hip) ---
 struct StemParams {

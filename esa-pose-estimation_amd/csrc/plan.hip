@@ -428,7 +428,7 @@ void group_multihead(esahrnet_ctx& c) {
 // branch by branch; here the convolutions of a module are put in depth-major order (stable, so every branch keeps its own
 // order) and the same-depth ones of up to three branches become a JobGroup.
 void group_jobs(esahrnet_ctx& c) {
-    if (getenv("ESAHRNET_NO_JOBS") || c.x6()) return;
+    if (getenv("ESAHRNET_NO_JOBS")) return;
     std::vector<Op> ops = c.ops;
     auto eligible = [&](const Op& o) {
         // the CBAM launches of a depth (seg_hrnet3): same kind on every branch, one launch (cbam.hip: cbam_jobs_kernel)
@@ -989,6 +989,15 @@ esa::ConvParams conv_params_of(const esahrnet_ctx& c, const Op& o, int n, const 
 bool job_on_for(const esahrnet_ctx& c, const JobGroup& g, int n, const std::vector<int>& lh, const std::vector<int>& lw) {
     if (c.ops[g.op[0]].kind != OP_CONV) return true;        // CBAM groups: the merged kernel runs every shape its members run
     esa::ConvParams ps[6];
+    if (c.x6()) {       // fp32-grade mode: conv_x6_jobs_kernel serves every kernel size / stride of the module
+        const ConvSpec& s0 = c.specs[c.dconvs[c.ops[g.op[0]].dconv].spec];
+        for (int k = 0; k < g.n; ++k) {
+            ps[k] = conv_params_of(c, c.ops[g.op[k]], n, lh, lw, nullptr);
+            const ConvSpec& sk = c.specs[c.dconvs[c.ops[g.op[k]].dconv].spec];
+            if (sk.k != s0.k || sk.stride != s0.stride) return false;
+        }
+        return esa::conv_x6_jobs_supported(ps, g.n, s0.k, s0.stride);
+    }
     if (c.specs[c.dconvs[c.ops[g.op[0]].dconv].spec].k == 1) {
         for (int k = 0; k < g.n; ++k) ps[k] = conv_params_of(c, c.ops[g.op[k]], n, lh, lw, nullptr);
         return esa::conv1x1_jobs_supported(ps, g.n);
@@ -1661,7 +1670,8 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                     const JobGroup& g = h->jobs[o.job];
                     esa::ConvParams ps[6];
                     for (int k = 0; k < g.n; ++k) ps[k] = conv_params_of(*h, h->ops[g.op[k]], n, sp.lh, sp.lw, ws);
-                    rc = s.k == 1 ? esa::launch_conv1x1_jobs(ps, g.n, stream) : esa::launch_conv_jobs(ps, g.n, s.stride, stream);
+                    rc = h->x6() ? esa::launch_conv_x6_jobs(ps, g.n, s.k, s.stride, stream)
+                       : s.k == 1 ? esa::launch_conv1x1_jobs(ps, g.n, stream) : esa::launch_conv_jobs(ps, g.n, s.stride, stream);
                     break;
                 }
                 const esa::ConvParams p = conv_params_of(*h, o, n, sp.lh, sp.lw, ws);
@@ -1888,7 +1898,8 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                     snprintf(out->label, sizeof out->label, "%s (in the merged launch above)", s.name.c_str());
                     break;
                 }
-                if (s.k == 1) snprintf(out->kernel, sizeof out->kernel, "conv1x1_jobs_kernel");
+                if (h->x6()) snprintf(out->kernel, sizeof out->kernel, "conv_x6_jobs_kernel<%d, %d>", s.k, s.stride);
+                else if (s.k == 1) snprintf(out->kernel, sizeof out->kernel, "conv1x1_jobs_kernel");
                 else snprintf(out->kernel, sizeof out->kernel, "conv_s2c32_jobs_kernel<%d, %d, %s>", s.stride, s.stride == 1 ? 8 : 4, h->bf ? "true" : "false");
                 std::string lab;
                 for (int k = 0; k < g.n; ++k) {

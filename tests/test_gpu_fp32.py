@@ -339,3 +339,31 @@ def test_fused_head_and_its_materialised_alternative(env, golden_dir, monkeypatc
         env["hrnet_ref"].forward(sd, cfg, x, tr)
         for name in ("head0", "head3"):
             assert (taps[name].cpu() - tr[name]).abs().max().item() <= 2e-5 * max(1.0, tr[name].abs().max().item()), name
+
+
+@pytest.mark.parametrize("no_jobs", [False, True])
+def test_merged_branch_launches_and_their_fallback(env, golden_dir, monkeypatch, no_jobs):
+    """The same-depth 3x3 convolutions of an HRModule's branches, the same-depth links of its fuse-down chains and its
+    fuse-up 1x1s are independent (models/seg_hrnet.py:143-220) and run as ONE launch of conv_x6_jobs_kernel each;
+    ESAHRNET_NO_JOBS=1 keeps one launch per convolution.  Same items, same order, same bits: the two plans must agree
+    bit for bit, and both with the reference."""
+    g = np.load(os.path.join(golden_dir, "w32_hrnet2_128.npz"), allow_pickle=False)
+    x = env["synth"].make_crops(int(g["n"]), 1, int(g["hw"]), int(g["hw"]), seed=int(g["seed"]))
+    outs = {}
+    for nj in (no_jobs, not no_jobs):
+        if nj:
+            monkeypatch.setenv("ESAHRNET_NO_JOBS", "1")
+        else:
+            monkeypatch.delenv("ESAHRNET_NO_JOBS", raising=False)
+        net, sd = _build(env, "seg_hrnet2", tuple(int(v) for v in g["widths"]), int(g["seed"]))
+        with torch.no_grad():
+            y, ops = net.forward_timed(x.cuda())
+        kernels = [o["kernel"] for o in ops]
+        merged = [o for o in ops if o["kernel"].startswith("conv_x6_jobs_kernel")]
+        assert bool(merged) == (not nj), kernels
+        assert all(" + " in o["label"] and o["flops"] > 0 for o in merged)
+        outs[nj] = (y.cpu(), len(ops))
+    print(f"launches: merged plan {outs[False][1]}, one per convolution {outs[True][1]}")
+    assert outs[False][1] < outs[True][1]
+    assert torch.equal(outs[False][0], outs[True][0])
+    assert np.abs(outs[no_jobs][0].numpy() - g["out"]).max() <= 2e-5

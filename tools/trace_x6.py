@@ -65,3 +65,18 @@ for b in range(G):
     cu.setdefault(key, []).append(b)
 pairs = [v for v in cu.values() if len(v) == 2]
 print(f"  {len(pairs)} CU slots with exactly two traced workgroups; of them {sum(1 for a, b in pairs if (a < G // 2) != (b < G // 2))} pair the two halves of the grid")
+
+d = (wg[:G, 1] - wg[:G, 0]) * 0.01
+xcc = (wg[:G, 3] >> 0) & 0  # placeholder
+print("duration (us) by workgroup index decile:", " ".join(f"{d[i * G // 10:(i + 1) * G // 10].mean():.0f}" for i in range(10)))
+print("workgroup 0 duration", f"{d[0]:.1f}", "min", f"{d.min():.1f}", "max", f"{d.max():.1f}")
+hw = wg[:G, 3]
+for name, sh, w in (("se_id", 13, 3), ("cu_id", 8, 4), ("sh_id", 12, 1)):
+    v = (hw >> sh) & ((1 << w) - 1)
+    print(name, " ".join(f"{int(k)}:{d[v == k].mean():.0f}" for k in np.unique(v)))
+
+for b in (0, 1, 7, 33):
+    pro = (int(t[b, 0, 7]) - int(wg[b, 0])) * 0.01
+    last = max(s_ for s_ in range(32) if t[b, s_, 6])
+    loop = (int(t[b, last, 7]) - int(t[b, 0, 7])) * 0.01
+    print(f"workgroup {b}: prologue {pro:.1f} us, steps 0..{last - 1} {loop:.1f} us, whole {d[b]:.1f} us")
