@@ -668,8 +668,6 @@ int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream) {
     }
 }
 
-#define X6_STR2(...) #__VA_ARGS__
-#define X6_STR(...) X6_STR2(__VA_ARGS__)
 // 2..6 independent convolutions of one kernel size and stride (each one a conv_x6 launch on its own) as ONE launch
 bool conv_x6_jobs_supported(const ConvParams* ps, int n, int k, int stride) {
     if (X6_MODE != 2 || n < 2 || n > X6_MAXJOBS) return false;
@@ -685,20 +683,22 @@ int launch_conv_x6_jobs(const ConvParams* ps, int n, int k, int stride, hipStrea
 }
 
 const char* conv_x6_kernel_name(const ConvParams& p, int k, int stride) {
-    // (as rocprofv3 prints the instantiation: the evaluated template arguments)
-    static char names[2][5][48];
-    static bool init = false;
-    if (!init) {
-        const int nr1[5] = {4, 2, 8, 16, 8}, ct[5] = {4, 2, 4, 4, 2}, st[5] = {2, 2, 1, 1, 1};
-        for (int kk = 0; kk < 2; ++kk)
-            for (int v = 0; v < 5; ++v) {
-                const int KS_ = kk ? 1 : 3, S_ = st[v], CT_ = ct[v], NR1_ = nr1[v];
-                const int a[6] = {X6_KARGS(KS_, S_, CT_, NR1_)};
-                snprintf(names[kk][v], sizeof names[kk][v], "conv_x6_kernel<%d, %d, %d, %d, %d, %d>", a[0], a[1], a[2], a[3], a[4], a[5]);
-            }
-        init = true;
-    }
-    return names[k == 3 ? 0 : 1][x6_variant(p, k, stride)];
+    // as rocprofv3 prints the instantiations of launch_conv_x6 (X6_KARGS evaluated), by x6_variant
+#if X6_MODE == 2
+    static const char* const n3[] = {"conv_x6_kernel<3, 2, 4, 2, 4, 2>", "conv_x6_kernel<3, 2, 2, 1, 4, 2>", "conv_x6_kernel<3, 1, 4, 8, 4, 2>",
+                                     "conv_x6_kernel<3, 1, 4, 8, 4, 2>", "conv_x6_kernel<3, 1, 2, 4, 4, 2>"};
+    static const char* const n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 8, 4, 2>", "conv_x6_kernel<1, 1, 4, 8, 4, 2>", "conv_x6_kernel<1, 1, 2, 4, 4, 2>"};
+#elif X6_MODE == 1
+    static const char* const n3[] = {"conv_x6_kernel<3, 2, 4, 2, 8, 1>", "conv_x6_kernel<3, 2, 2, 1, 8, 1>", "conv_x6_kernel<3, 1, 4, 4, 8, 1>",
+                                     "conv_x6_kernel<3, 1, 4, 8, 8, 1>", "conv_x6_kernel<3, 1, 2, 4, 8, 1>"};
+    static const char* const n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 4, 8, 1>", "conv_x6_kernel<1, 1, 4, 8, 8, 1>", "conv_x6_kernel<1, 1, 2, 4, 8, 1>"};
+#else
+    static const char* const n3[] = {"conv_x6_kernel<3, 2, 4, 4, 4, 1>", "conv_x6_kernel<3, 2, 2, 2, 4, 1>", "conv_x6_kernel<3, 1, 4, 8, 4, 1>",
+                                     "conv_x6_kernel<3, 1, 4, 16, 4, 1>", "conv_x6_kernel<3, 1, 2, 8, 4, 1>"};
+    static const char* const n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 8, 4, 1>", "conv_x6_kernel<1, 1, 4, 16, 4, 1>", "conv_x6_kernel<1, 1, 2, 8, 4, 1>"};
+#endif
+    const int v = x6_variant(p, k, stride);
+    return k == 3 ? n3[v] : n1[v];
 }
 
 }  // namespace esa

@@ -190,6 +190,7 @@ struct esahrnet_ctx {
     }
     bool fuse_big = true;       // fused stem + fused head (ESAHRNET_UNFUSED=1 selects the op-by-op plan)
     bool head2_enabled = true;  // ESAHRNET_HEAD_V1=1 keeps the first-generation fused head for every shape
+    bool cbam_unfused = false;  // ESAHRNET_CBAM_UNFUSED=1: cbam_maps + cbam_apply instead of cbam_spatial
     int head2_op = -1;          // index of the OP_HEAD2 op, -1 if the plan has none
     // wave executor (schedule_waves): the launches of a wave that do not depend on each other run on up to four lanes
     // (the caller's stream + three side streams), fork/join through the caller's stream at every wave boundary
@@ -1017,6 +1018,18 @@ int plan_shape(esahrnet_ctx& c, int n, int h, int w) {
     ShapePlan sp;
     sp.n = n; sp.h = h; sp.w = w; sp.keep = c.keep;
     level_dims(c, h, w, sp.lh, sp.lw);
+    // seg_hrnet3's head by linearity (head_gather.hip) stages the tap-product windows of two branches in LDS: a shape it
+    // cannot serve is refused HERE with a message, not by a failed launch in the middle of a forward
+    for (const Op& o : c.ops)
+        if (o.kind == OP_GATHER) {
+            const Tensor& to = c.tensors[o.out];
+            const int zt[2] = {o.in, o.terms[0]};
+            int zh[2], zw[2];
+            for (int b = 0; b < 2; ++b) { zh[b] = sp.lh[c.tensors[zt[b]].level]; zw[b] = sp.lw[c.tensors[zt[b]].level]; }
+            if (!esa::head_gather_supported(sp.lh[to.level], sp.lw[to.level], zh, zw, to.Cp))
+                return fail("crop %dx%d: the interpolation windows of seg_hrnet3's last_layer[0] do not fit the gather kernel's LDS "
+                            "budget (set ESAHRNET_HEAD3_DIRECT=1 before creating the net for the direct 480-channel 3x3)", h, w);
+        }
     sp.head2 = head2_for_shape(c, sp.lh, sp.lw, &sp.head2_ulo);
     const int active_alt = sp.head2 ? 2 : 1;
     sp.multi_on.assign(c.multis.size(), 0);
@@ -1162,6 +1175,14 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
         if (cfg->modules[s] < 1) return fail("NUM_MODULES of stage %d must be >= 1", s + 1);
     for (int b = 0; b < ESAHRNET_MAX_BRANCHES; ++b)
         if (cfg->blocks[3][b] > 0 && cfg->widths[b] < 1) return fail("width of branch %d must be positive", b);
+    // the job keys of group_jobs pack (stage << 4 | module) above an 8-bit depth field in which the branch convolutions take
+    // (2 or 6) * block + 0..5, the fuse-up 1x1s 100 and the fuse-down links 128 + k: reject stage tables that overflow either
+    for (int s = 0; s < 4; ++s) {
+        if (cfg->modules[s] > 15) return fail("NUM_MODULES of stage %d is %d (at most 15)", s + 1, cfg->modules[s]);
+        for (int b = 0; b < ESAHRNET_MAX_BRANCHES; ++b)
+            if ((cfg->variant == 1 ? 6 : 2) * cfg->blocks[s][b] + (cfg->variant == 1 ? 5 : 1) >= 100)
+                return fail("NUM_BLOCKS of stage %d branch %d is %d (at most %d)", s + 1, b, cfg->blocks[s][b], cfg->variant == 1 ? 15 : 49);
+    }
     esahrnet_ctx* c = new esahrnet_ctx();
     c->cfg = *cfg;
     c->device = device;
@@ -1177,6 +1198,7 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     }
     if (const char* e = getenv("ESAHRNET_STREAMS")) c->nlanes = atoi(e) > 1 ? 4 : 1;
     if (const char* e = getenv("ESAHRNET_HEAD_V1")) c->head2_enabled = !(e[0] && e[0] != '0');
+    c->cbam_unfused = getenv("ESAHRNET_CBAM_UNFUSED") != nullptr;
     if (build_plan(*c)) { delete c; return 1; }
     *out = c;
     return 0;
@@ -1441,8 +1463,9 @@ static int stem_pools(const esahrnet_ctx& c, int height, int width) {
     return slabs <= STEM_POOL_SLABS_MAX ? slabs : 0;
 }
 
-static bool cbam_fused(int Cp, int hh, int ww) {
-    return esa::cbam_spatial_supported(Cp) && ((hh + 15) / 16) * ((ww + 31) / 32) >= 32 && !getenv("ESAHRNET_CBAM_UNFUSED");
+// (ESAHRNET_CBAM_UNFUSED is read once, at esahrnet_create, like the other plan switches — not per launch)
+static bool cbam_fused(const esahrnet_ctx& c, int Cp, int hh, int ww) {
+    return esa::cbam_spatial_supported(Cp) && ((hh + 15) / 16) * ((ww + 31) / 32) >= 32 && !c.cbam_unfused;
 }
 
 static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, int width,
@@ -1491,13 +1514,13 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 q.w0 = h->aux[o.aux[0]].dev; q.w2 = h->aux[o.aux[1]].dev;
                 break;
             case OP_MAPS:
-                if (cbam_fused(tx.Cp, hh, ww)) break;
+                if (cbam_fused(*h, tx.Cp, hh, ww)) break;
                 q.kind = esa::CBAM_MAPS; q.ap.x = T(o.in); q.ap.ca = reinterpret_cast<const float*>(T(o.terms[1]));
                 q.maps = reinterpret_cast<float*>(T(o.out));
                 break;
             default: {
                 const Tensor& to = h->tensors[o.out];
-                q.kind = cbam_fused(tx.Cp, hh, ww) ? esa::CBAM_SPATIAL : esa::CBAM_APPLY;
+                q.kind = cbam_fused(*h, tx.Cp, hh, ww) ? esa::CBAM_SPATIAL : esa::CBAM_APPLY;
                 q.ap.x = T(o.in); q.ap.res = o.res >= 0 ? T(o.res) : nullptr;
                 q.ap.ca = reinterpret_cast<const float*>(T(o.terms[1])); q.ap.maps = reinterpret_cast<const float*>(T(o.terms[2]));
                 q.ap.w_sa = h->aux[o.aux[2]].dev; q.ap.y = T(o.out);
@@ -1574,7 +1597,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
             }
             case OP_MAPS: {
                 const Tensor& ti = h->tensors[o.in];
-                if (cbam_fused(ti.Cp, sp.lh[ti.level], sp.lw[ti.level])) break;      // formed inside cbam_spatial (the OP_APPLY that follows)
+                if (cbam_fused(*h, ti.Cp, sp.lh[ti.level], sp.lw[ti.level])) break;      // formed inside cbam_spatial (the OP_APPLY that follows)
                 rc = esa::launch_cbam_maps(T(o.in), reinterpret_cast<const float*>(T(o.terms[1])),
                                            reinterpret_cast<float*>(T(o.out)), n, sp.lh[ti.level] * sp.lw[ti.level],
                                            o.nchan, ti.Cp, stream);
@@ -1589,7 +1612,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 p.w_sa = h->aux[o.aux[2]].dev; p.y = T(o.out);
                 p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level]; p.Cp = ti.Cp;
                 p.y_pix_bytes = to.Cp * 4; p.y_c0 = o.c0; p.relu = o.relu; p.C = o.nchan;
-                rc = cbam_fused(ti.Cp, p.H, p.W) ? esa::launch_cbam_spatial(p, stream) : esa::launch_cbam_apply(p, stream);
+                rc = cbam_fused(*h, ti.Cp, p.H, p.W) ? esa::launch_cbam_spatial(p, stream) : esa::launch_cbam_apply(p, stream);
                 break;
             }
             default: break;
@@ -2008,7 +2031,7 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                 // merged launch of the group (run_forward): issued at the first member, for every member that launches at all
                 const JobGroup& g = h->jobs[o.job];
                 auto folded = [&](const Op& ok) {
-                    return ok.kind == OP_MAPS && cbam_fused(h->tensors[ok.in].Cp, lh[h->tensors[ok.in].level], lw[h->tensors[ok.in].level]);
+                    return ok.kind == OP_MAPS && cbam_fused(*h, h->tensors[ok.in].Cp, lh[h->tensors[ok.in].level], lw[h->tensors[ok.in].level]);
                 };
                 int launching = 0;
                 for (int k = 0; k < g.n; ++k) launching += folded(h->ops[g.op[k]]) ? 0 : 1;
@@ -2027,7 +2050,7 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                 break;
             }
             if ((o.kind == OP_MAPS || o.kind == OP_APPLY) &&
-                cbam_fused(h->tensors[o.in].Cp, lh[h->tensors[o.in].level], lw[h->tensors[o.in].level])) {
+                cbam_fused(*h, h->tensors[o.in].Cp, lh[h->tensors[o.in].level], lw[h->tensors[o.in].level])) {
                 if (o.kind == OP_MAPS) { out->kernel[0] = 0; snprintf(out->label, sizeof out->label, "(inside cbam_spatial)"); break; }
                 snprintf(out->kernel, sizeof out->kernel, "cbam_spatial");
             }

@@ -575,9 +575,10 @@ def test_hrnet3_cbam_forms_agree(env, monkeypatch):
         y1, ops1 = net1.forward_timed(x)
     assert not any(o["kernel"].startswith("cbam_jobs") for o in ops1)
     assert torch.equal(y1, y)
-    monkeypatch.setenv("ESAHRNET_CBAM_UNFUSED", "1")
+    monkeypatch.setenv("ESAHRNET_CBAM_UNFUSED", "1")      # (a plan switch: read when the handle is created)
+    net2, _ = _build(env, "seg_hrnet3", (32, 64, 128, 256), 13)
     with torch.no_grad():
-        y2, ops2 = net1.forward_timed(x)
+        y2, ops2 = net2.forward_timed(x)
     assert "cbam_spatial" not in {o["kernel"] for o in ops2} and "cbam_maps" in {o["kernel"] for o in ops2}
     assert (y2 - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
     # plan-time alternatives of the same handle family: pooling of the raw stem tensor by pool_partial instead of inside

@@ -62,3 +62,53 @@ def test_sampler_matches_reference_values():
     g = pnp._SplitMix(0)
     s = g.sample(11, 5)
     assert len(set(s)) == 5 and all(0 <= v < 11 for v in s)
+
+
+# ---- an INDEPENDENT checker for the weighted refinement --------------------------------------------------
+# scipy.optimize.least_squares (MINPACK / trust-region, numerical Jacobian) minimises the SAME residuals — peak-weighted
+# reprojection errors over a 6-vector [angle-axis, t] (uncertainty_pnp.cpp:7-33 with wxx = wyy = peak, wxy = 0) — built
+# here from scipy's own Rotation class: no line of pnp.py or pnp_host.hip is involved in the reference value.  The stage
+# stays "parity unpinned" against cpnp / Ceres (absent); this pins it against a second, unrelated optimiser.
+def _scipy_refine(p3d, p2d, w, cam0):
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+
+    def res(x):
+        pc = Rotation.from_rotvec(x[:3]).apply(p3d) + x[3:]
+        u = K[0, 0] * pc[:, 0] / pc[:, 2] + K[0, 2]
+        v = K[1, 1] * pc[:, 1] / pc[:, 2] + K[1, 2]
+        return (w[:, None] * (np.stack([u, v], 1) - p2d)).ravel()
+
+    sol = least_squares(res, cam0, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-15, x_scale="jac", max_nfev=2000)
+    return sol.x, float(sol.fun @ sol.fun)
+
+
+@pytest.mark.parametrize("k,noise", [(11, 0.0), (11, 0.7), (30, 1.5)])
+def test_weighted_refinement_reaches_scipys_minimum(k, noise):
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(900 + k)
+    n = 8
+    kp3d, kp, boxes, rates, poses = _scene(rng, n, k, noise, 0)
+    q_nat, t_nat = pnp.keypoints_to_pose_batch(kp, kp3d, K, boxes, rates, thresh=0.0, min_k=k, threads=2)
+    for i in range(n):
+        ori = kp[i, :, :2].astype(np.float64) / rates[i] + np.asarray(boxes[i], np.float64)      # val.py:180
+        w = kp[i, :, 2].astype(np.float64)
+        Rt, tt = poses[i]
+        # start scipy from a perturbed truth (its basin is the pose's): the minimiser of the weighted cost
+        cam0 = np.concatenate([Rotation.from_matrix(Rt).as_rotvec() + rng.normal(0, 0.01, 3), tt * (1 + rng.normal(0, 0.01, 3))])
+        x_ref, cost_ref = _scipy_refine(kp3d, ori, w, cam0)
+
+        def cost_of(q, t):
+            R = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()
+            pc = kp3d @ R.T + t
+            uv = np.stack([K[0, 0] * pc[:, 0] / pc[:, 2] + K[0, 2], K[1, 1] * pc[:, 1] / pc[:, 2] + K[1, 2]], 1)
+            r = (w[:, None] * (uv - ori)).ravel()
+            return float(r @ r)
+
+        q_np, t_np, _ = pnp.keypoints_to_pose(kp[i], kp3d, K, boxes[i], rates[i], thresh=0.0, min_k=k)
+        for name, (q, t) in (("native", (q_nat[i], t_nat[i])), ("numpy", (q_np, t_np))):
+            c = cost_of(q, t)
+            assert c <= cost_ref * (1 + 1e-6) + 1e-12, (name, i, c, cost_ref)           # as deep a minimum as scipy's
+            q_ref = Rotation.from_rotvec(x_ref[:3]).as_quat()                           # [x, y, z, w]
+            s = pnp.speed_score(q, t, np.array([q_ref[3], q_ref[0], q_ref[1], q_ref[2]]), x_ref[3:])[0]
+            assert s < (1e-6 if noise == 0 else 2e-4), (name, i, s)                     # and the same pose
