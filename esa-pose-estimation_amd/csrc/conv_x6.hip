@@ -176,8 +176,17 @@ struct X6Pos {            // one (item, chunk) step of the workgroup's stream
     bool ok;
 };
 
-template <int KS, int S, int CT, int NR, int NW>
-__device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, const int bid, const int G) {
+// STEM (fused stem, launch_stem_fused_x6): the input tensor of this 3x3 stride-2 convolution — conv1 + bn1 + ReLU of the raw
+// crop (models/seg_hrnet.py:426-428), 64 channels at full resolution: 537 MB per batch-32 step written and read back — is
+// never materialised.  A staging unit loads the 3x3 neighbourhood of its pixel from the f32 NCHW crop (cin = 1) and forms
+// its 8 channels on the f32 VALU (bias first, then the nine taps in order: bit for bit what stem_kernel computes), ReLU,
+// then splits them like any other unit.  Everything behind the staging is the ordinary kernel.
+struct X6StemSrc {
+    const float* x0;      // f32 [N][1][H][W]
+    const float* w1;      // f32 [2 chunks][4 k-groups][9 taps + bias][8]: channel chunk*32 + x6_chan_of_k(sg, j)
+};
+template <int KS, int S, int CT, int NR, int NW, bool STEM = false>
+__device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, const int bid, const int G, const X6StemSrc stem = X6StemSrc{}) {
     using C = X6Cfg<KS, S, CT, NR, NW>;
     constexpr int QSTEP = C::NT / 4;            // tile pixels staged per iteration
     constexpr int TAPS = C::TAPS, ROWS = C::ROWS, XITER = C::XITER;
@@ -215,6 +224,10 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         return q;
     };
 
+    float* const w1s = reinterpret_cast<float*>(smem + C::LDS);     // STEM: conv1's folded weights + bias, [chunk][sg][10][8]
+    if (STEM) {
+        for (int i = tid; i < 2 * 4 * 10 * 8; i += C::NT) w1s[i] = stem.w1[i];      // (published by the loop's first barrier)
+    }
     // ---- staging map: thread -> (k-group sg, tile pixel q0 + QSTEP*it), fixed for the launch ----
     const int sg = tid & 3, q0 = tid >> 2;
     int qyx[XITER];                             // tile-local (row << 8 | column), -1 beyond the tile
@@ -227,9 +240,30 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     // The tile of step s+1 is staged INSIDE step s in two halves (units [0, XH) and [XH, XITER)): loads at the start of a
     // phase, split + LDS writes behind it — a unit lives in registers for one phase, not for a whole step.
     constexpr int XH = KS == 1 ? XITER : (XITER + 1) / 2;
-    u32x4 xr[XH][2];                            // the half in flight: two quads of 4 channels per unit
+    u32x4 xr[STEM ? 1 : XH][2];                 // the half in flight: two quads of 4 channels per unit
+    float rawv[STEM ? XH : 1][9];               // STEM: the unit's 3x3 neighbourhood of the raw crop
+    uint32_t rmask[STEM ? XH : 1];              //       and ~0 / 0: is its pixel inside conv1's output (else conv2's zero padding)?
+    int rchunk = 0;                             //       channel chunk of the half in flight
     auto load_tile = [&](const X6Pos& q, auto half_c) __attribute__((always_inline)) {
         constexpr int i0 = decltype(half_c)::value * XH;
+        if constexpr (STEM) {
+            const uint32_t rimg = (uint32_t)p.H * p.W * 4;
+            const __amdgpu_buffer_rsrc_t rx = x6_rsrc(stem.x0 + (size_t)q.n * p.H * p.W, q.ok ? rimg : 0u);
+            const int gy0 = q.oy0 * S - C::PAD, gx0 = q.ox0 * S - C::PAD;
+            rchunk = q.c;
+#pragma unroll
+            for (int it = i0; it < i0 + XH && it < XITER; ++it) {
+                const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
+                rmask[it - i0] = (qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
+                    const bool in = qyx[it] >= 0 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                    rawv[it - i0][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, in ? (yy * p.W + xx) * 4 : (int)X6_OOB, 0, 0));
+                }
+            }
+            return;
+        }
         const __amdgpu_buffer_rsrc_t rx = x6_rsrc(p.x + (size_t)q.n * ximg, q.ok ? ximg : 0u);      // (no step behind: zeros, no traffic)
         const int gy0 = q.oy0 * S - C::PAD, gx0 = q.ox0 * S - C::PAD;
         const int so = q.c * 128;
@@ -250,12 +284,32 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         {
             if (it >= XITER || (X6_ABL & 2)) return;
             u32x4 t0, t1, t2;
+            u32x4 src[2];
+            if constexpr (STEM) {       // conv1 + bn1 + ReLU of the unit's pixel, channels rchunk*32 + x6_chan_of_k(sg, 0..7)
+                const float* wt = w1s + (rchunk * 4 + sg) * 80;
+                f32x4 a0 = *reinterpret_cast<const f32x4*>(wt + 72), a1 = *reinterpret_cast<const f32x4*>(wt + 76);      // bias
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + t * 8), w1v = *reinterpret_cast<const f32x4*>(wt + t * 8 + 4);
+                    const float v = rawv[it - i0][t];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { a0[k] = fmaf(v, w0[k], a0[k]); a1[k] = fmaf(v, w1v[k], a1[k]); }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    src[0][k] = __float_as_uint(relu1(a0[k])) & rmask[it - i0];
+                    src[1][k] = __float_as_uint(relu1(a1[k])) & rmask[it - i0];
+                }
+            } else {
+                src[0] = xr[it - i0][0];
+                src[1] = xr[it - i0][1];
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     uint32_t a, b, c;
-                    x6_split_pair(__uint_as_float(xr[it - i0][h][2 * k]), __uint_as_float(xr[it - i0][h][2 * k + 1]), a, b, c);
+                    x6_split_pair(__uint_as_float(src[h][2 * k]), __uint_as_float(src[h][2 * k + 1]), a, b, c);
                     t0[2 * h + k] = a; t1[2 * h + k] = b; t2[2 * h + k] = c;
                 }
             char* o = xwr + buf * C::XBYTES + it * (QSTEP * 16);
@@ -505,6 +559,11 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void conv_x6_kernel(ConvPara
     x6_body<KS, S, CT, NR, NW>(p, geo, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// fused stem: conv1 (VALU, inside the staging) -> conv2 3x3 stride 2 (models/seg_hrnet.py:426-431), cin = 1
+__global__ __launch_bounds__(NTHREADS, 2) void stem_x6_kernel(ConvParams p, X6Geo geo, X6StemSrc stem) {
+    x6_body<3, 2, 4, 2, 4, true>(p, geo, (int)blockIdx.x, (int)gridDim.x, stem);
+}
+
 // Several INDEPENDENT convolutions of one kind (the same-depth 3x3s of an HRModule's branches, the same-depth links of its
 // fuse-down chains, its fuse-up 1x1s: models/seg_hrnet.py:143-220 — none reads another's output) in one launch.
 // Workgroups [start[j], start[j+1]) run convolution j exactly as its own launch would — same items per workgroup, same
@@ -666,6 +725,50 @@ int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream) {
         case 3: return launch_x6_t<X6_KARGS(1, 1, 4, 16)>(p, stream);
         default: return launch_x6_t<X6_KARGS(1, 1, 2, 8)>(p, stream);
     }
+}
+
+// ---- fused stem of the fp32-grade mode ----------------------------------------------------------------------------------
+bool stem_fused_x6_supported(int cin, int cmid, int coutp) { return X6_MODE == 2 && cin == 1 && cmid == 64 && coutp % 64 == 0; }
+
+// conv1's folded weights [64][1][3][3] + bias [64] -> [2 chunks][4 k-groups][9 taps + bias][8] f32 (X6StemSrc::w1)
+void pack_stem_w1_x6(const float* w, const float* b, float* dst) {
+    for (int c = 0; c < 2; ++c)
+        for (int sg = 0; sg < 4; ++sg)
+            for (int j = 0; j < 8; ++j) {
+                const int ch = c * 32 + x6_chan_of_k(sg, j);
+                float* o = dst + (c * 4 + sg) * 80;
+                for (int t = 0; t < 9; ++t) o[t * 8 + j] = w[ch * 9 + t];
+                o[72 + j] = b[ch];
+            }
+}
+
+int launch_stem_fused_x6(const StemFusedParams& sp, hipStream_t stream) {
+    if (!stem_fused_x6_supported(sp.cin, sp.Cmid, sp.Coutp)) return (int)hipErrorInvalidValue;
+    using C = X6Cfg<3, 2, 4, 2, 4>;
+    ConvParams p{};
+    p.x = nullptr; p.y = sp.y; p.res = nullptr; p.w = sp.w2; p.bias = sp.bias2;
+    p.N = sp.N; p.H = sp.H; p.W = sp.W; p.OH = sp.OH; p.OW = sp.OW; p.Cinp = sp.Cmid; p.Coutp = sp.Coutp; p.relu = 1; p.fmt = FMT_F32;
+    if (sp.OH != (sp.H + 1) / 2 || sp.OW != (sp.W + 1) / 2 || (long long)sp.H * sp.W * 4 >= 0x7fffffffLL ||
+        (long long)sp.OH * sp.OW * sp.Coutp * 4 >= 0x7fffffffLL)
+        return (int)hipErrorInvalidValue;
+    X6Geo geo;
+    geo.tiles_x = (p.OW + TW - 1) / TW;
+    geo.tiles_y = (p.OH + C::TH - 1) / C::TH;
+    geo.ctiles = p.Coutp / 64;
+    const long long nitems = (long long)p.N * geo.tiles_y * geo.tiles_x * geo.ctiles;
+    if (nitems <= 0 || nitems > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    geo.nitems = (int)nitems;
+    geo.m_ct = x6_magic(geo.ctiles);
+    geo.m_tx = x6_magic(geo.tiles_x);
+    geo.m_ty = x6_magic(geo.tiles_y);
+    const int slots = 2 * device_cus();
+    int grid = (int)(nitems < slots ? nitems : slots);
+    if (grid > geo.ctiles) grid -= grid % geo.ctiles;
+    constexpr int LDS = C::LDS + 2 * 4 * 10 * 8 * 4;
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(stem_x6_kernel), LDS)) return e_;
+    X6StemSrc src{sp.x, sp.w1};
+    hipLaunchKernelGGL(stem_x6_kernel, dim3((unsigned)grid), dim3(NTHREADS), LDS, stream, p, geo, src);
+    return (int)hipGetLastError();
 }
 
 // 2..6 independent convolutions of one kernel size and stride (each one a conv_x6 launch on its own) as ONE launch

@@ -118,6 +118,11 @@ struct StemFusedParams {
     int N, H, W, OH, OW, cin, Cmid, Coutp;
 };
 int launch_stem_fused(const StemFusedParams& p, hipStream_t stream);
+// fp32-grade mode (conv_x6.hip): x f32 NCHW, y f32 NHWC, w1 = pack_stem_w1_x6 image (conv1 folded weights + bias, 640 floats),
+// w2 = pack_conv_weights_x6 of conv2; cin == 1 only
+bool stem_fused_x6_supported(int cin, int cmid, int coutp);
+void pack_stem_w1_x6(const float* w, const float* b, float* dst);
+int launch_stem_fused_x6(const StemFusedParams& p, hipStream_t stream);
 
 // ---- cross-resolution fuse: y = relu?(sum_i up(x_i)) on SB tensors (fuse.hip) ---------------
 struct FuseParams {

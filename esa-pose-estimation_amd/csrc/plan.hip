@@ -190,6 +190,7 @@ struct esahrnet_ctx {
     }
     bool fuse_big = true;       // fused stem + fused head (ESAHRNET_UNFUSED=1 selects the op-by-op plan)
     bool head2_enabled = true;  // ESAHRNET_HEAD_V1=1 keeps the first-generation fused head for every shape
+    bool x6_stemf = false;      // fp32-grade mode: conv1 inside conv2's staging (stem_x6_kernel), cin == 1
     bool cbam_unfused = false;  // ESAHRNET_CBAM_UNFUSED=1: cbam_maps + cbam_apply instead of cbam_spatial
     int head2_op = -1;          // index of the OP_HEAD2 op, -1 if the plan has none
     // wave executor (schedule_waves): the launches of a wave that do not depend on each other run on up to four lanes
@@ -615,7 +616,7 @@ int build_plan_ops(esahrnet_ctx& c) {
         Op o; o.kind = OP_STEMF; o.dconv = (int)c.dconvs.size() - 1; o.out = B.tensor(sw, 1, "stem2");
         B.push(o);
         x = o.out;
-    } else if (c.fuse_big) {       // conv1 recomputed per tile inside the conv2 kernel (stem_fused.hip)
+    } else if (c.fuse_big || c.x6_stemf) {       // conv1 recomputed per tile inside the conv2 kernel (stem_fused.hip / conv_x6.hip)
         DevConv d;
         d.spec = spec_conv2; d.c0 = 0; d.c1 = sw; d.use_bias = true;
         d.cinp = pad32(sw); d.coutp = pad32(sw);
@@ -1195,6 +1196,8 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     if (cfg->precision == 2) {      // fp32-grade mode: f32 NHWC tensors, bf16x6 arithmetic (conv_x6.hip); op-by-op plan
         c->fmt = esa::FMT_F32;
         c->fuse_big = false;
+        c->x6_stemf = esa::stem_fused_x6_supported(cfg->cin, pad32(cfg->stem_width), pad32(cfg->stem_width)) && cfg->stem_width == 64 &&
+                      !getenv("ESAHRNET_X6_UNFUSED_STEM");
     }
     if (const char* e = getenv("ESAHRNET_STREAMS")) c->nlanes = atoi(e) > 1 ? 4 : 1;
     if (const char* e = getenv("ESAHRNET_HEAD_V1")) c->head2_enabled = !(e[0] && e[0] != '0');
@@ -1353,6 +1356,11 @@ int esahrnet_commit(esahrnet_handle h) {
             for (int ci = 0; ci < s.cin; ++ci)
                 for (int t = 0; t < 9; ++t)
                     w[(((size_t)(co >> 3) * s.cin + ci) * 9 + t) * 8 + (co & 7)] = s.w[((size_t)co * s.cin + ci) * 9 + t];
+        }
+        if (h->x6_stemf) {      // stem_x6_kernel reads conv1 in its own layout (bias inside)
+            std::vector<float> wx(2 * 4 * 10 * 8, 0.f);
+            esa::pack_stem_w1_x6(s.w.data(), s.b.data(), wx.data());
+            w = wx;
         }
         if (upload(w, reinterpret_cast<void**>(&h->stem_w)) || upload(b, reinterpret_cast<void**>(&h->stem_b))) return 1;
     }
@@ -1661,7 +1669,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 p.w2 = static_cast<const uint4*>(d.w); p.bias2 = d.bias;
                 p.N = n; p.H = height; p.W = width; p.OH = sp.lh[to.level]; p.OW = sp.lw[to.level];
                 p.cin = h->cfg.cin; p.Cmid = d.cinp; p.Coutp = d.coutp;
-                rc = esa::launch_stem_fused(p, stream);
+                rc = h->x6() ? esa::launch_stem_fused_x6(p, stream) : esa::launch_stem_fused(p, stream);
                 break;
             }
             case OP_CONV: {
@@ -1882,12 +1890,12 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
             const ConvSpec& s1 = h->specs[h->spec_stem];
             const ConvSpec& s2 = h->specs[h->dconvs[o.dconv].spec];
             const Tensor& to = h->tensors[o.out];
-            snprintf(out->kernel, sizeof out->kernel, "stem_fused");
+            snprintf(out->kernel, sizeof out->kernel, h->x6() ? "stem_x6_kernel" : "stem_fused");
             snprintf(out->label, sizeof out->label, "conv1 + conv2");
             out->flops = 2.0 * n * height * width * s1.cout * s1.cin * 9 +
                          2.0 * n * lh[to.level] * lw[to.level] * s2.cout * s2.cin * 9;
             out->bytes = (double)n * height * width * s1.cin * 4 + tbytes(o.out) +
-                         (double)esa::packed_weight_bytes(pad32(s2.cout), pad32(s2.cin), 3);
+                         (double)h->wbytes(pad32(s2.cout), pad32(s2.cin), 3);
             break;
         }
         case OP_CONV: {

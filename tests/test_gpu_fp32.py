@@ -241,7 +241,7 @@ def test_intermediate_tensors_match_oracle(env):
         taps = net.taps(x.cuda())
     torch.cuda.synchronize()
     worst = 0.0
-    assert {"stem1", "stem2", "layer1", "stage2.0", "stage3.2", "stage4.0", "stage4.3"} <= set(taps)
+    assert {"stem2", "layer1", "stage2.0", "stage3.2", "stage4.0", "stage4.3"} <= set(taps)
     for name, ref in taps_ref.items():
         if name not in taps:
             continue
@@ -367,3 +367,32 @@ def test_merged_branch_launches_and_their_fallback(env, golden_dir, monkeypatch,
     assert outs[False][1] < outs[True][1]
     assert torch.equal(outs[False][0], outs[True][0])
     assert np.abs(outs[no_jobs][0].numpy() - g["out"]).max() <= 2e-5
+
+
+def test_fused_stem_is_bit_identical_to_conv1_then_conv2(env, golden_dir, monkeypatch):
+    """stem_x6_kernel forms conv1 + bn1 + ReLU inside conv2's staging (the 64-channel full-resolution tensor is never written):
+    same f32 operations in the same order as stem_kernel, so the two plans agree bit for bit; seg_hrnet (3-channel crops)
+    keeps the two-kernel stem."""
+    g = np.load(os.path.join(golden_dir, "w32_hrnet2_128.npz"), allow_pickle=False)
+    x = env["synth"].make_crops(3, 1, 96, 80, seed=9)
+    outs = []
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("ESAHRNET_X6_UNFUSED_STEM", "1")
+        net, sd = _build(env, "seg_hrnet2", (32, 64, 128, 256), 9)
+        with torch.no_grad():
+            y, ops = net.forward_timed(x.cuda())
+            taps = net.taps(x.cuda())
+        kernels = [o["kernel"] for o in ops]
+        assert ("stem_x6_kernel" in kernels) == (not unfused) and ("stem_kernel" in kernels) == unfused, kernels[:3]
+        assert ("stem1" in taps) == unfused
+        outs.append((y.cpu(), taps["stem2"].cpu()))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+    with torch.no_grad():
+        ref = env["hrnet_ref"].forward(sd, env["hrnet_ref"].default_cfg(1, 11), x)
+    assert (outs[0][0] - ref).abs().max().item() <= 2e-5
+    monkeypatch.delenv("ESAHRNET_X6_UNFUSED_STEM")
+    net3, _ = _build(env, "seg_hrnet", (16, 32, 64, 128), 9)
+    with torch.no_grad():
+        _, ops3 = net3.forward_timed(env["synth"].make_crops(1, 3, 64, 64, seed=9).cuda())
+    assert ops3[0]["kernel"] == "stem_kernel"
