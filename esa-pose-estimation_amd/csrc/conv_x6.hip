@@ -710,6 +710,7 @@ static int x6_variant(const ConvParams& p, int k, int stride) {
 #endif
 int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream) {
     if (!conv_x6_supported(p, k, stride)) return (int)hipErrorInvalidValue;
+    if (k == 1 && conv1x1_x6_supported(p)) return launch_conv1x1_x6(p, stream);
     const int v = x6_variant(p, k, stride);
     if (k == 3) {
         switch (v) {
@@ -725,6 +726,154 @@ int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream) {
         case 3: return launch_x6_t<X6_KARGS(1, 1, 4, 16)>(p, stream);
         default: return launch_x6_t<X6_KARGS(1, 1, 2, 8)>(p, stream);
     }
+}
+
+// ---- 1x1 convolutions with all input channels of a wave's pixels in registers (conv1x1_x6_kernel) -----------------------
+// The tile-stream kernel above stages the input once per (tile, 32- or 64-cout slice): a 1x1 with 480 couts (the
+// last_layer[0] slices on the low-resolution branches, models/seg_hrnet.py:313-321 after the linearity trick) re-reads and
+// re-splits its input fifteen times for steps of 24-48 MFMAs.  Here — the structure of conv1x1.hip in bf16x6 arithmetic —
+// a wave owns PG groups of 16 pixels of a row, loads ALL their input channels once (two quads per chunk, x6 K order),
+// splits them once into the three exact bf16 terms (registers for the whole launch), and walks the output channels 16 at
+// a time; the weight fragments of a cout tile (3 * NCH KB) stream through a double-buffered LDS image shared by the four
+// waves.  Per cout tile the 6 * NCH products run as one chain from a fresh accumulator, low-order products first.
+template <int NCH, int PG>
+__device__ __forceinline__ void x6_c1_body(const ConvParams& p, const long long ntiles, const int tiles_per_row, const int bid, const int G) {
+    constexpr int WFR = 3 * NCH;                    // 1-KB weight fragments per 16-cout tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    bool valid[PG];
+    size_t pixel[PG];                               // (n*H + y) * W + x of the lane's pixel in group pg
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+        const long long tile = ((long long)xcd_contiguous(bid, G) * 4 + wave) * PG + pg;
+        const int k = (int)(tile % tiles_per_row);
+        const long long row = tile / tiles_per_row;
+        const int col = k * 16 + i;
+        valid[pg] = tile < ntiles && col < p.W;
+        pixel[pg] = (size_t)row * p.W + col;
+    }
+    bf16x8 xf[PG][NCH][3];
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+            if (valid[pg]) {
+                const float* a = reinterpret_cast<const float*>(p.x) + pixel[pg] * (size_t)p.Cinp + c * 32 + g * 4;
+                lo = *reinterpret_cast<const f32x4*>(a);
+                hi = *reinterpret_cast<const f32x4*>(a + 16);
+            }
+            u32x4 t[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float va = k < 2 ? lo[2 * k] : hi[2 * k - 4], vb = k < 2 ? lo[2 * k + 1] : hi[2 * k - 3];
+                uint32_t h_, m_, l_;
+                x6_split_pair(va, vb, h_, m_, l_);
+                t[0][k] = h_; t[1][k] = m_; t[2][k] = l_;
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xf[pg][c][q] = __builtin_bit_cast(bf16x8, t[q]);
+        }
+    constexpr int WIT = (WFR * 64 + NTHREADS - 1) / NTHREADS;
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
+    u32x4 wreg[WIT];
+    auto prefetch = [&](int m) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (it * NTHREADS + tid < WFR * 64) wreg[it] = wsrc[(size_t)m * WFR * 64 + it * NTHREADS + tid];
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (it * NTHREADS + tid < WFR * 64) *reinterpret_cast<u32x4*>(smem + buf * (WFR * 1024) + (it * NTHREADS + tid) * 16) = wreg[it];
+    };
+    const int ntile16 = p.Coutp >> 4;
+    prefetch(0);
+    commit(0);
+    __syncthreads();
+    const int rfl = relu_floor(p.relu);
+    for (int m = 0; m < ntile16; ++m) {
+        const int buf = m & 1;
+        if (m + 1 < ntile16) prefetch(m + 1);
+        const char* wb = smem + buf * (WFR * 1024) + lane * 16;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + m * 16 + g * 4);
+        f32x4 d[PG];
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) d[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            bf16x8 wa[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wa[q] = *reinterpret_cast<const bf16x8*>(wb + (c * 3 + q) * 1024);
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) {
+                d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2], xf[pg][c][0], d[pg], 0, 0, 0);
+                d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], xf[pg][c][2], d[pg], 0, 0, 0);
+                d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], xf[pg][c][1], d[pg], 0, 0, 0);
+                d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], xf[pg][c][0], d[pg], 0, 0, 0);
+                d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], xf[pg][c][1], d[pg], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wb + (c * 3) * 1024);
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) d[pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xf[pg][c][0], d[pg], 0, 0, 0);
+        }
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) {
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(relu_opt(d[pg][k] + bv[k], rfl));
+            if (valid[pg]) *reinterpret_cast<u32x4*>(p.y + (pixel[pg] * (size_t)p.Coutp + m * 16 + g * 4) * 4) = o;
+        }
+        if (m + 1 < ntile16) {
+            commit(buf ^ 1);
+            __syncthreads();
+        }
+    }
+}
+
+template <int NCH, int PG>
+__global__ __launch_bounds__(NTHREADS, 2) void conv1x1_x6_kernel(ConvParams p, long long ntiles, int tiles_per_row) {
+    x6_c1_body<NCH, PG>(p, ntiles, tiles_per_row, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// the fuse-up 1x1 convolutions of an HRModule (models/seg_hrnet.py:176-197) in one launch
+constexpr int X6_C1_MAXJOBS = 6;
+struct X6C1Jobs {
+    ConvParams p[X6_C1_MAXJOBS];
+    long long ntiles[X6_C1_MAXJOBS];
+    int tiles_per_row[X6_C1_MAXJOBS];
+    int start[X6_C1_MAXJOBS + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(NTHREADS, 2) void conv1x1_x6_jobs_kernel(X6C1Jobs jobs) {
+    const int b = (int)blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < X6_C1_MAXJOBS; ++k) j += (k < jobs.njobs && b >= jobs.start[k]) ? 1 : 0;
+    const int bid = b - jobs.start[j], G = jobs.start[j + 1] - jobs.start[j];
+    const ConvParams& p = jobs.p[j];
+    switch (p.Cinp >> 5) {
+        case 2: x6_c1_body<2, 1>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G); break;
+        case 4: x6_c1_body<4, 1>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G); break;
+        default: x6_c1_body<8, 1>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G); break;
+    }
+}
+
+template <int NCH, int PG>
+int launch_c1_x6_t(const ConvParams& p, hipStream_t stream) {
+    const int lds = 2 * 3 * NCH * 1024;
+    const int tiles_per_row = (p.W + 15) / 16;
+    const long long ntiles = (long long)p.N * p.H * tiles_per_row;
+    const long long nblk = (ntiles + 4 * PG - 1) / (4 * PG);
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    auto kern = conv1x1_x6_kernel<NCH, PG>;
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTHREADS), lds, stream, p, ntiles, tiles_per_row);
+    return (int)hipGetLastError();
 }
 
 // ---- fused stem of the fp32-grade mode ----------------------------------------------------------------------------------
@@ -771,6 +920,57 @@ int launch_stem_fused_x6(const StemFusedParams& sp, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// 1x1 with 64 / 128 / 256 (or 32 / 96 / 192) input channels and no residual: the register-resident form
+bool conv1x1_x6_supported(const ConvParams& p) {
+    const int n = p.Cinp / 32;
+    // measured (batch 32): 64 -> 480 on a 64x64 grid 135 -> 85 us, but 128 -> 480 on 32x32 62 -> 72 and 256 -> 480 on 16x16
+    // 31 -> 44 (a workgroup walks all cout tiles serially: small grids want the tile-stream kernel's cout slices side by
+    // side) — so: wide outputs on grids of at least 2048 pixels per image (a rule on the shape, never on the batch)
+    return p.fmt == FMT_F32 && !p.res && !p.out_f32 && p.nheads <= 1 && (p.Cinp % 32) == 0 && (p.Coutp % 16) == 0 && p.H == p.OH &&
+           p.W == p.OW && (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8) && (long long)p.H * p.W >= 2048 && p.Coutp >= 64 &&
+           !getenv("ESAHRNET_X6_NO_C1");
+}
+int launch_conv1x1_x6(const ConvParams& p, hipStream_t stream) {
+    if (!conv1x1_x6_supported(p)) return (int)hipErrorInvalidValue;
+    switch (p.Cinp / 32) {
+        case 1: return launch_c1_x6_t<1, 2>(p, stream);
+        case 2: return launch_c1_x6_t<2, 2>(p, stream);
+        case 3: return launch_c1_x6_t<3, 2>(p, stream);
+        case 4: return launch_c1_x6_t<4, 2>(p, stream);
+        case 6: return launch_c1_x6_t<6, 1>(p, stream);
+        default: return launch_c1_x6_t<8, 1>(p, stream);
+    }
+}
+bool conv1x1_x6_jobs_supported(const ConvParams* ps, int n) {
+    if (n < 2 || n > X6_C1_MAXJOBS || !getenv("ESAHRNET_X6_C1_JOBS")) return false;      // (fuse-up 1x1s: 24 -> 30, 32 -> 48 us; opt-in)
+    for (int j = 0; j < n; ++j) {
+        const int nch = ps[j].Cinp / 32;
+        if (!conv1x1_x6_supported(ps[j]) || (nch != 2 && nch != 4 && nch != 8)) return false;
+    }
+    return true;
+}
+int launch_conv1x1_x6_jobs(const ConvParams* ps, int n, hipStream_t stream) {
+    if (!conv1x1_x6_jobs_supported(ps, n)) return (int)hipErrorInvalidValue;
+    X6C1Jobs jobs{};
+    jobs.njobs = n;
+    int at = 0;
+    for (int j = 0; j < n; ++j) {
+        const ConvParams& p = ps[j];
+        jobs.p[j] = p;
+        jobs.tiles_per_row[j] = (p.W + 15) / 16;
+        jobs.ntiles[j] = (long long)p.N * p.H * jobs.tiles_per_row[j];
+        const long long nblk = (jobs.ntiles[j] + 3) / 4;
+        if (nblk <= 0 || at + nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        jobs.start[j] = at;
+        at += (int)nblk;
+    }
+    for (int k = n; k <= X6_C1_MAXJOBS; ++k) jobs.start[k] = at;
+    const int lds = 2 * 3 * 8 * 1024;
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(conv1x1_x6_jobs_kernel), lds)) return e_;
+    hipLaunchKernelGGL(conv1x1_x6_jobs_kernel, dim3((unsigned)at), dim3(NTHREADS), lds, stream, jobs);
+    return (int)hipGetLastError();
+}
+
 // 2..6 independent convolutions of one kernel size and stride (each one a conv_x6 launch on its own) as ONE launch
 bool conv_x6_jobs_supported(const ConvParams* ps, int n, int k, int stride) {
     if (X6_MODE != 2 || n < 2 || n > X6_MAXJOBS) return false;
@@ -781,6 +981,7 @@ bool conv_x6_jobs_supported(const ConvParams* ps, int n, int k, int stride) {
 
 int launch_conv_x6_jobs(const ConvParams* ps, int n, int k, int stride, hipStream_t stream) {
     if (!conv_x6_jobs_supported(ps, n, k, stride)) return (int)hipErrorInvalidValue;
+    if (k == 1 && conv1x1_x6_jobs_supported(ps, n)) return launch_conv1x1_x6_jobs(ps, n, stream);
     if (k == 1) return launch_x6_jobs_t<1, 1>(ps, n, stream);
     return stride == 1 ? launch_x6_jobs_t<3, 1>(ps, n, stream) : launch_x6_jobs_t<3, 2>(ps, n, stream);
 }
@@ -800,6 +1001,7 @@ const char* conv_x6_kernel_name(const ConvParams& p, int k, int stride) {
                                      "conv_x6_kernel<3, 1, 4, 16, 4, 1>", "conv_x6_kernel<3, 1, 2, 8, 4, 1>"};
     static const char* const n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 8, 4, 1>", "conv_x6_kernel<1, 1, 4, 16, 4, 1>", "conv_x6_kernel<1, 1, 2, 8, 4, 1>"};
 #endif
+    if (k == 1 && conv1x1_x6_supported(p)) return "conv1x1_x6_kernel";
     const int v = x6_variant(p, k, stride);
     return k == 3 ? n3[v] : n1[v];
 }

@@ -78,6 +78,12 @@ const char* conv_x6_kernel_name(const ConvParams& p, int k, int stride);
 // 2..6 independent convolutions of one kernel size and stride on FMT_F32 tensors as ONE launch (conv_x6_jobs_kernel)
 bool conv_x6_jobs_supported(const ConvParams* ps, int n, int k, int stride);
 int launch_conv_x6_jobs(const ConvParams* ps, int n, int k, int stride, hipStream_t stream);
+// 1x1 with all input channels of a wave's pixels in registers (<= 256 input channels, no residual); launch_conv_x6 routes here
+bool conv1x1_x6_supported(const ConvParams& p);
+int launch_conv1x1_x6(const ConvParams& p, hipStream_t stream);
+int launch_conv1x1_x6_jobs(const ConvParams* ps, int n, hipStream_t stream);
+// does launch_conv_x6_jobs(k = 1) run the register-resident 1x1 kernel (conv1x1_x6_jobs_kernel) for these members?
+bool conv1x1_x6_jobs_supported(const ConvParams* ps, int n);
 
 // ---- stem conv1: f32 NCHW -> SB, 3x3 s1, cin in {1..4}, cout = multiple of 32 (stem.hip) ---
 struct StemParams {

@@ -1929,7 +1929,12 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                     snprintf(out->label, sizeof out->label, "%s (in the merged launch above)", s.name.c_str());
                     break;
                 }
-                if (h->x6()) snprintf(out->kernel, sizeof out->kernel, "conv_x6_jobs_kernel<%d, %d>", s.k, s.stride);
+                if (h->x6()) {
+                    esa::ConvParams qs[6];
+                    for (int k = 0; k < g.n; ++k) qs[k] = conv_params_of(*h, h->ops[g.op[k]], n, lh, lw, nullptr);
+                    if (s.k == 1 && esa::conv1x1_x6_jobs_supported(qs, g.n)) snprintf(out->kernel, sizeof out->kernel, "conv1x1_x6_jobs_kernel");
+                    else snprintf(out->kernel, sizeof out->kernel, "conv_x6_jobs_kernel<%d, %d>", s.k, s.stride);
+                }
                 else if (s.k == 1) snprintf(out->kernel, sizeof out->kernel, "conv1x1_jobs_kernel");
                 else snprintf(out->kernel, sizeof out->kernel, "conv_s2c32_jobs_kernel<%d, %d, %s>", s.stride, s.stride == 1 ? 8 : 4, h->bf ? "true" : "false");
                 std::string lab;
