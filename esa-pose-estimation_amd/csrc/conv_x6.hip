@@ -52,6 +52,9 @@ extern "C" int esa_debug_x6_wg(void* dst) { return (int)hipMemcpyFromSymbol(dst,
 #ifndef X6_ABL
 #define X6_ABL 0
 #endif
+#ifndef X6_DEEP
+#define X6_DEEP 0
+#endif
 #ifndef X6_PRIO_FLIP
 #define X6_PRIO_FLIP 1
 #endif
@@ -239,8 +242,15 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     }
     // The tile of step s+1 is staged INSIDE step s in two halves (units [0, XH) and [XH, XITER)): loads at the start of a
     // phase, split + LDS writes behind it — a unit lives in registers for one phase, not for a whole step.
-    constexpr int XH = KS == 1 ? XITER : (XITER + 1) / 2;
+    // DEEP (stride 2 and 1x1: steps of 24-108 MFMAs per wave, shorter than a trip to HBM): the WHOLE tile of step s+2 is
+    // loaded at the start of step s into a second register set (xn) and handed to xr at the start of step s+1 — two steps of
+    // cover instead of one phase.  Measured (X6_DEEP=1): no change — the stride-2 steps (36 MFMAs per phase and wave) are bound
+    // by what surrounds the MFMAs (item decode, address generation, 27 weight loads, barrier: 5 k of a step's 7 k cycles), not
+    // by load latency.  Off by default.
+    constexpr bool DEEP = !STEM && (S == 2 || KS == 1) && X6_DEEP;
+    constexpr int XH = (KS == 1 || DEEP) ? XITER : (XITER + 1) / 2;
     u32x4 xr[STEM ? 1 : XH][2];                 // the half in flight: two quads of 4 channels per unit
+    u32x4 xn[DEEP ? XITER : 1][2];              // DEEP: the tile two steps ahead
     float rawv[STEM ? XH : 1][9];               // STEM: the unit's 3x3 neighbourhood of the raw crop
     uint32_t rmask[STEM ? XH : 1];              //       and ~0 / 0: is its pixel inside conv1's output (else conv2's zero padding)?
     int rchunk = 0;                             //       channel chunk of the half in flight
@@ -276,6 +286,19 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                 xr[it - i0][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so, 0);
                 xr[it - i0][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so + 64, 0);
             }
+        }
+    };
+    auto load_next = [&](const X6Pos& q) __attribute__((always_inline)) {       // DEEP: all units of q's tile -> xn
+        const __amdgpu_buffer_rsrc_t rx = x6_rsrc(p.x + (size_t)q.n * ximg, q.ok ? ximg : 0u);
+        const int gy0 = q.oy0 * S - C::PAD, gx0 = q.ox0 * S - C::PAD;
+        const int so = q.c * 128;
+#pragma unroll
+        for (int it = 0; it < (DEEP ? XITER : 0); ++it) {
+            const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
+            const bool inside = qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const uint32_t off = inside ? (uint32_t)((gy * p.W + gx) * pixb + sg * 16) : X6_OOB;
+            xn[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so, 0);
+            xn[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so + 64, 0);
         }
     };
     char* const xwr = smem + q0 * 16 + sg * (3 * C::PLANE) + (S == 2 ? (sg & 1) * 16 : 0);      // plane_off(sg, 0) + pixel slot
@@ -352,6 +375,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         write_tile(0, H1);
     }
     X6Pos nxt = advance(cur);
+    if constexpr (DEEP) load_next(nxt);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) load_w(cur.ct, 0, kx);
@@ -366,8 +390,8 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     int pstep = 0;
 #ifdef X6_TRACE
     int tstep = 0;
-    const bool ton = KS == 3 && S == 1 && bid < 64 && tid == 0;
-    const bool wgon = KS == 3 && S == 1 && bid < 1024 && tid == 0;
+    const bool ton = KS == 3 && S == X6_TRACE && bid < 64 && tid == 0;
+    const bool wgon = KS == 3 && S == X6_TRACE && bid < 1024 && tid == 0;
     if (wgon) {
         g_x6_wg[bid * 4] = __builtin_amdgcn_s_memrealtime();
         g_x6_wg[bid * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -513,7 +537,13 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             // 0 / 1, split + LDS writes in those phases' last rows.  The weight third a phase has used is refilled for step
             // s+1 right behind it.  (The sched_barriers keep hipcc from hoisting those loads into the phase before: the
             // registers they fill are the ones that phase is still reading.)
-            load_tile(nxt, H0);
+            if constexpr (DEEP) {
+#pragma unroll
+                for (int it = 0; it < XITER; ++it) { xr[it][0] = xn[it][0]; xr[it][1] = xn[it][1]; }
+                load_next(advance(nxt));
+            } else {
+                load_tile(nxt, H0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             X6_TR(2)
             phase(std::integral_constant<int, 0>{}, F, W0);
@@ -531,7 +561,13 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             X6_TR(5)
             load_w(wct, wch, 2);
         } else {
-            load_tile(nxt, H0);
+            if constexpr (DEEP) {
+#pragma unroll
+                for (int it = 0; it < XITER; ++it) { xr[it][0] = xn[it][0]; xr[it][1] = xn[it][1]; }
+                load_next(advance(nxt));
+            } else {
+                load_tile(nxt, H0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             phase(std::integral_constant<int, 0>{}, T, W0);
             asm volatile("" : "+v"(bvn));

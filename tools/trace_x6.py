@@ -12,16 +12,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from esa_pose_estimation_amd import _lib, synth  # noqa: E402
 
 n, cin, cout, h, w = [int(v) for v in (sys.argv[1:6] if len(sys.argv) > 5 else (128, 64, 64, 64, 64))]
+stride = int(sys.argv[6]) if len(sys.argv) > 6 else 1        # build with -DX6_TRACE=<stride>
 lib = _lib.lib()
 raw = C.CDLL(_lib.LIB_PATH) if hasattr(_lib, "LIB_PATH") else lib
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 x = torch.from_numpy(synth.normal("x", 1, (n, cin, h, w))).cuda()
 wt = synth.normal("w", 2, (cout, cin, 3, 3), float(np.sqrt(1.0 / (cin * 9))))
 b = synth.normal("b", 3, (cout,), 0.1)
-y = torch.empty((n, cout, h, w), device="cuda")
+y = torch.empty((n, cout, (h + stride - 1) // stride, (w + stride - 1) // stride), device="cuda")
 for _ in range(2):
     _lib.check(lib.esahrnet_op_conv_ex(x.data_ptr(), n, cin, h, w, wt.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
-                                       cout, 3, 1, 1, None, y.data_ptr(), 2, st))
+                                       cout, 3, stride, 1, None, y.data_ptr(), 2, st))
 torch.cuda.synchronize()
 buf = np.zeros(64 * 32 * 8, np.uint64)
 fn = raw.esa_debug_x6_trace
