@@ -254,6 +254,20 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     float rawv[STEM ? XH : 1][9];               // STEM: the unit's 3x3 neighbourhood of the raw crop
     uint32_t rmask[STEM ? XH : 1];              //       and ~0 / 0: is its pixel inside conv1's output (else conv2's zero padding)?
     int rchunk = 0;                             //       channel chunk of the half in flight
+    // byte offsets of the staged item's units inside its image (X6_OOB beyond the image: the zero padding); they change with
+    // the item, not with the chunk: recomputed by tile_offsets() when the stream moves to a new item
+    uint32_t xoff[STEM ? 1 : XITER];
+    auto tile_offsets = [&](const X6Pos& q) __attribute__((always_inline)) {
+        if constexpr (!STEM) {
+            const int gy0 = q.oy0 * S - C::PAD, gx0 = q.ox0 * S - C::PAD;
+#pragma unroll
+            for (int it = 0; it < XITER; ++it) {
+                const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
+                const bool inside = qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                xoff[it] = inside ? (uint32_t)((gy * p.W + gx) * pixb + sg * 16) : X6_OOB;
+            }
+        }
+    };
     auto load_tile = [&](const X6Pos& q, auto half_c) __attribute__((always_inline)) {
         constexpr int i0 = decltype(half_c)::value * XH;
         if constexpr (STEM) {
@@ -275,13 +289,10 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             return;
         }
         const __amdgpu_buffer_rsrc_t rx = x6_rsrc(p.x + (size_t)q.n * ximg, q.ok ? ximg : 0u);      // (no step behind: zeros, no traffic)
-        const int gy0 = q.oy0 * S - C::PAD, gx0 = q.ox0 * S - C::PAD;
         const int so = q.c * 128;
 #pragma unroll
         for (int it = i0; it < i0 + XH && it < XITER; ++it) {
-            const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
-            const bool inside = qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            const uint32_t off = inside ? (uint32_t)((gy * p.W + gx) * pixb + sg * 16) : X6_OOB;
+            const uint32_t off = xoff[STEM ? 0 : it];
             if (!(X6_ABL & 1)) {
                 xr[it - i0][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so, 0);
                 xr[it - i0][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so + 64, 0);
@@ -368,6 +379,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
 #pragma unroll
         for (int it = i0; it < i0 + XH; ++it) write_unit(buf, i0, it);
     };
+    tile_offsets(cur);
     load_tile(cur, H0);
     write_tile(0, H0);
     if constexpr (XH < XITER) {
@@ -375,6 +387,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         write_tile(0, H1);
     }
     X6Pos nxt = advance(cur);
+    if (nxt.c == 0) tile_offsets(nxt);
     if constexpr (DEEP) load_next(nxt);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -584,6 +597,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         if (!nxt.ok) break;
         cur = nxt;
         nxt = advance(cur);
+        if (nxt.c == 0) tile_offsets(nxt);      // (a uniform branch around integer VALU only)
         buf ^= 1;
     }
 }
