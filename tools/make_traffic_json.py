@@ -31,7 +31,7 @@ for f in sorted(glob.glob(os.path.join(root, "pass*", "*", "*_counter_collection
                 cut = i
                 break
         fn = fn[:cut]
-        if fn.startswith(("conv_s2c32_kernel", "conv_s2c32_jobs_kernel", "conv_mfma_ring_kernel", "conv_mfma_kernel")):
+        if fn.startswith(("conv_s2c32_kernel", "conv_s2c32_jobs_kernel", "conv_mfma_ring_kernel", "conv_mfma_kernel", "conv_x6_kernel", "conv_x6_jobs_kernel")):
             key = fn
         else:
             key = fn.split("<")[0].replace("_kernel", "")
