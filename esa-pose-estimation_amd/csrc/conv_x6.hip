@@ -518,9 +518,12 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                     // registers, then bursts of adds)
                     asm volatile("" : "+v"(acc[r - 1]));
                     if constexpr (EPI) {          // row r - 1 leaves
-                        u32x4 eo;
+                        u32x4 eo = {0u, 0u, 0u, 0u};
+                        if (last_chunk) {         // (a uniform branch around VALU only: the store below stays unconditional — its
+                                                  // offset is out of range when the step does not end its item)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) eo[k] = __float_as_uint(relu_opt(acc[r - 1][k] + __uint_as_float(rc[(r - 1) % RCN][k]), rfl));
+                            for (int k = 0; k < 4; ++k) eo[k] = __float_as_uint(relu_opt(acc[r - 1][k] + __uint_as_float(rc[(r - 1) % RCN][k]), rfl));
+                        }
                         const uint32_t so = (r - 1) < nrows ? o0 + (uint32_t)((r - 1) * orow) : X6_OOB;
                         // (image base in the descriptor, scalar offset the constant 0: see the store-data hazard note in
                         // conv_s2c32.hip — hipcc pads 16-byte buffer stores only when they carry no SGPR soffset)
