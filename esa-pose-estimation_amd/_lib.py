@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libesahrnet.so")
 MAX_BRANCHES = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Cfg(C.Structure):

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define ESAHRNET_MAX_BRANCHES 4
-#define ESAHRNET_ABI_VERSION 4
+#define ESAHRNET_ABI_VERSION 5      /* 5: esahrnet_cfg.precision 2 (fp32-grade bf16x6) */
 
 typedef struct esahrnet_ctx* esahrnet_handle;
 typedef void* esahrnet_stream; /* hipStream_t */
