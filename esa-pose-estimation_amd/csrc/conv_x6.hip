@@ -52,6 +52,9 @@ extern "C" int esa_debug_x6_wg(void* dst) { return (int)hipMemcpyFromSymbol(dst,
 #ifndef X6_ABL
 #define X6_ABL 0
 #endif
+#ifndef X6_S2_SINGLE
+#define X6_S2_SINGLE 1    // stride-2 kernels (and the fused stem): 4-row tiles in ONE LDS buffer, two barriers per step
+#endif
 #ifndef X6_DEEP
 #define X6_DEEP 0
 #endif
@@ -142,7 +145,11 @@ __host__ __device__ constexpr int x6_first_unit_in_row(int NR, int XH, int nunit
     return 0;
 }
 
-template <int KS, int S, int CT, int NR, int NW>
+// NBUF: tile buffers in LDS.  2: the tile of step s+1 is written while step s computes, ONE barrier per step.  1 (stride 2:
+// the input tile is 4x the output tile, and 4-row tiles double-buffered leave room for one workgroup per CU only): the
+// whole next tile is loaded into registers during the step and written between two barriers behind it — the write phase
+// (split, or the fused stem's conv1: pure VALU) of one workgroup runs beside the MFMA phases of the CU's other one.
+template <int KS, int S, int CT, int NR, int NW, int NBUF = 2>
 struct X6Cfg {
     static constexpr int NT = NW * 64;                      // threads per workgroup (NW waves: 4 = one per SIMD, 8 = two)
     static constexpr int RG = NW / CT;                      // row groups
@@ -154,7 +161,7 @@ struct X6Cfg {
     static constexpr int NPIX = IH * IW;
     static constexpr int PLANE = ((NPIX * 16 + 128 + 255) / 256) * 256;
     static constexpr int XBYTES = 12 * PLANE;               // one tile buffer: 4 k-groups x 3 terms
-    static constexpr int LDS = 2 * XBYTES;
+    static constexpr int LDS = NBUF * XBYTES;
     static constexpr int XITER = (NPIX * 4 + NT - 1) / NT;
     static constexpr int ROWS = (NR - 1) * S + KS;          // input rows a wave touches
     // B-operand reads (ds_read_b128: lane groups pair k-groups {0,1} and {2,3}, one term per instruction) want the
@@ -188,9 +195,9 @@ struct X6StemSrc {
     const float* x0;      // f32 [N][1][H][W]
     const float* w1;      // f32 [2 chunks][4 k-groups][9 taps + bias][8]: channel chunk*32 + x6_chan_of_k(sg, j)
 };
-template <int KS, int S, int CT, int NR, int NW, bool STEM = false>
+template <int KS, int S, int CT, int NR, int NW, bool STEM = false, int NBUF = 2>
 __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, const int bid, const int G, const X6StemSrc stem = X6StemSrc{}) {
-    using C = X6Cfg<KS, S, CT, NR, NW>;
+    using C = X6Cfg<KS, S, CT, NR, NW, NBUF>;
     constexpr int QSTEP = C::NT / 4;            // tile pixels staged per iteration
     constexpr int TAPS = C::TAPS, ROWS = C::ROWS, XITER = C::XITER;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -247,8 +254,8 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     // cover instead of one phase.  Measured (X6_DEEP=1): no change — the stride-2 steps (36 MFMAs per phase and wave) are bound
     // by what surrounds the MFMAs (item decode, address generation, 27 weight loads, barrier: 5 k of a step's 7 k cycles), not
     // by load latency.  Off by default.
-    constexpr bool DEEP = !STEM && (S == 2 || KS == 1) && X6_DEEP;
-    constexpr int XH = (KS == 1 || DEEP) ? XITER : (XITER + 1) / 2;
+    constexpr bool DEEP = !STEM && NBUF == 2 && (S == 2 || KS == 1) && X6_DEEP;
+    constexpr int XH = (KS == 1 || DEEP || NBUF == 1) ? XITER : (XITER + 1) / 2;
     u32x4 xr[STEM ? 1 : XH][2];                 // the half in flight: two quads of 4 channels per unit
     u32x4 xn[DEEP ? XITER : 1][2];              // DEEP: the tile two steps ahead
     float rawv[STEM ? XH : 1][9];               // STEM: the unit's 3x3 neighbourhood of the raw crop
@@ -453,7 +460,8 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         const __amdgpu_buffer_rsrc_t rr = x6_rsrc((do_res ? p.res : p.y) + (size_t)cur.n * yimg, do_res ? yimg : 0u);
         const __amdgpu_buffer_rsrc_t ry = x6_rsrc(p.y + (size_t)cur.n * yimg, yimg);
         const int rfl = relu_floor(p.relu);
-        constexpr int RCN = NR < 6 ? NR : 6;       // residual rows in flight (a row's load is issued RCN - 1 rows before its epilogue)
+        constexpr int RCN = NBUF == 1 ? 2 : NR < 6 ? NR : 6;       // residual rows in flight (a row's load is issued RCN - 1 rows before its
+                                                                   // epilogue; the single-buffer stride-2 kernels are short of registers)
         u32x4 rc[RCN];
         // (unconditional: without a residual the descriptor is empty and the loads return zeros — a load behind a run-time
         // condition makes hipcc drain vmcnt(0) at the join)
@@ -475,7 +483,10 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             constexpr int kx = decltype(kx_c)::value;
             constexpr bool EPI = decltype(epi_c)::value;         // last phase of the item: rows leave as they complete
             constexpr int WH = decltype(wh_c)::value;
-            constexpr int RING = KS + S;                         // input rows of output rows r and r + 1
+            // LDS operand reads run one output row ahead (RING = the input rows of output rows r and r + 1) — except in the
+            // single-buffer stride-2 kernels, which are short of registers: there a row's new input rows are read at its start
+            constexpr bool PREF = NBUF == 2;
+            constexpr int RING = PREF ? KS + S : KS;
             constexpr int NSLOT = 6 * KS;                        // MFMAs of a row
             bf16x8 xw[RING][3];
             auto read_rows = [&](int lo, int hi) __attribute__((always_inline)) {
@@ -500,7 +511,8 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                 // (The wave issues in order and hipcc puts everything else behind the row's MFMAs; what fills the matrix pipe
                 // meanwhile is the SIMD's other wave.)
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (r + 1 < NR) read_rows(r * S + KS, (r + 1) * S + KS - 1);
+                if constexpr (PREF && r + 1 < NR) read_rows(r * S + KS, (r + 1) * S + KS - 1);
+                if constexpr (!PREF && r > 0 && r < NR) read_rows((r - 1) * S + KS, r * S + KS - 1);
                 if constexpr (r < NR) {
                     sm = f32x4{0.f, 0.f, 0.f, 0.f};
                     x6_static_for<0, NSLOT>([&](auto i_c) __attribute__((always_inline)) {
@@ -548,7 +560,26 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         constexpr auto W0 = std::integral_constant<int, 0>{};
         constexpr auto W1 = std::integral_constant<int, XH < XITER ? 1 : -1>{};
         constexpr auto WN = std::integral_constant<int, -1>{};
-        if constexpr (KS == 3) {
+        if constexpr (KS == 3 && NBUF == 1) {
+            // single tile buffer: the whole next tile -> registers now, -> LDS between the two barriers behind the phases
+            load_tile(nxt, H0);
+            __builtin_amdgcn_sched_barrier(0);
+            X6_TR(2)
+            phase(std::integral_constant<int, 0>{}, F, WN);
+            asm volatile("" : "+v"(bvn));
+            X6_TR(3)
+            load_w(wct, wch, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(std::integral_constant<int, 1>{}, F, WN);
+            X6_TR(4)
+            load_w(wct, wch, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(std::integral_constant<int, 2>{}, T, WN);
+            X6_TR(5)
+            load_w(wct, wch, 2);
+            __syncthreads();            // every wave is done reading the tile
+            write_tile(0, H0);          // (published by the barrier at the top of the next step)
+        } else if constexpr (KS == 3) {
             // The tile of step s+1 goes to the other buffer (free since the barrier) half by half: loads at the start of phases
             // 0 / 1, split + LDS writes in those phases' last rows.  The weight third a phase has used is refilled for step
             // s+1 right behind it.  (The sched_barriers keep hipcc from hoisting those loads into the phase before: the
@@ -601,20 +632,24 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         cur = nxt;
         nxt = advance(cur);
         if (nxt.c == 0) tile_offsets(nxt);      // (a uniform branch around integer VALU only)
-        buf ^= 1;
+        if constexpr (NBUF == 2) buf ^= 1;
     }
 }
 
 // OCC: workgroups per CU the register / LDS budget is cut for
-template <int KS, int S, int CT, int NR, int NW, int OCC>
+template <int KS, int S, int CT, int NR, int NW, int OCC, int NBUF>
 __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void conv_x6_kernel(ConvParams p, X6Geo geo) {
-    static_assert(OCC * X6Cfg<KS, S, CT, NR, NW>::LDS <= 160 * 1024, "tile buffers of OCC workgroups exceed the CU's LDS");
-    x6_body<KS, S, CT, NR, NW>(p, geo, (int)blockIdx.x, (int)gridDim.x);
+    static_assert(OCC * X6Cfg<KS, S, CT, NR, NW, NBUF>::LDS <= 160 * 1024, "tile buffers of OCC workgroups exceed the CU's LDS");
+    x6_body<KS, S, CT, NR, NW, false, NBUF>(p, geo, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // fused stem: conv1 (VALU, inside the staging) -> conv2 3x3 stride 2 (models/seg_hrnet.py:426-431), cin = 1
+constexpr int X6_S2_NBUF = X6_S2_SINGLE ? 1 : 2;        // stride 2: 4-row tiles in one LDS buffer / 2-row tiles in two
+constexpr int X6_S2_NR4 = X6_S2_SINGLE ? 4 : 2, X6_S2_NR2 = X6_S2_SINGLE ? 2 : 1;
+// the stem keeps 2-row tiles in two buffers: its staging holds 9 raw pixels per unit and the 4-row tile's 5 units spill
+constexpr int X6_STEM_NR = 2, X6_STEM_NBUF = 2;
 __global__ __launch_bounds__(NTHREADS, 2) void stem_x6_kernel(ConvParams p, X6Geo geo, X6StemSrc stem) {
-    x6_body<3, 2, 4, 2, 4, true>(p, geo, (int)blockIdx.x, (int)gridDim.x, stem);
+    x6_body<3, 2, 4, X6_STEM_NR, 4, true, X6_STEM_NBUF>(p, geo, (int)blockIdx.x, (int)gridDim.x, stem);
 }
 
 // Several INDEPENDENT convolutions of one kind (the same-depth 3x3s of an HRModule's branches, the same-depth links of its
@@ -633,9 +668,10 @@ struct X6Jobs {
 };
 template <int KS, int S>
 struct X6JobCfg {
-    static constexpr int NR4 = S == 2 ? 2 : 8, NR2 = S == 2 ? 1 : 4;      // rows per wave of the 64- / 32-cout tiling (X6_MODE 2)
-    using C4 = X6Cfg<KS, S, 4, NR4, 4>;
-    using C2 = X6Cfg<KS, S, 2, NR2, 4>;
+    static constexpr int NR4 = S == 2 ? X6_S2_NR4 : 8, NR2 = S == 2 ? X6_S2_NR2 : 4;      // rows per wave of the 64- / 32-cout tiling (X6_MODE 2)
+    static constexpr int NBUF = S == 2 ? X6_S2_NBUF : 2;
+    using C4 = X6Cfg<KS, S, 4, NR4, 4, NBUF>;
+    using C2 = X6Cfg<KS, S, 2, NR2, 4, NBUF>;
     static constexpr int LDS = C4::LDS > C2::LDS ? C4::LDS : C2::LDS;
 };
 template <int KS, int S>
@@ -645,8 +681,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_x6_jobs_kernel(X6Jobs jobs) 
 #pragma unroll
     for (int k = 1; k < X6_MAXJOBS; ++k) j += (k < jobs.njobs && b >= jobs.start[k]) ? 1 : 0;
     const int bid = b - jobs.start[j], G = jobs.start[j + 1] - jobs.start[j];
-    if (jobs.ct[j] == 4) x6_body<KS, S, 4, X6JobCfg<KS, S>::NR4, 4>(jobs.p[j], jobs.geo[j], bid, G);
-    else x6_body<KS, S, 2, X6JobCfg<KS, S>::NR2, 4>(jobs.p[j], jobs.geo[j], bid, G);
+    if (jobs.ct[j] == 4) x6_body<KS, S, 4, X6JobCfg<KS, S>::NR4, 4, false, X6JobCfg<KS, S>::NBUF>(jobs.p[j], jobs.geo[j], bid, G);
+    else x6_body<KS, S, 2, X6JobCfg<KS, S>::NR2, 4, false, X6JobCfg<KS, S>::NBUF>(jobs.p[j], jobs.geo[j], bid, G);
 }
 
 uint32_t x6_magic(int d) { return (uint32_t)(0xffffffffull / (uint64_t)d); }
@@ -696,9 +732,9 @@ int launch_x6_jobs_t(const ConvParams* ps, int n, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-template <int KS, int S, int CT, int NR, int NW, int OCC>
+template <int KS, int S, int CT, int NR, int NW, int OCC, int NBUF>
 int launch_x6_t(const ConvParams& p, hipStream_t stream) {
-    using C = X6Cfg<KS, S, CT, NR, NW>;
+    using C = X6Cfg<KS, S, CT, NR, NW, NBUF>;
     X6Geo geo;
     geo.tiles_x = (p.OW + TW - 1) / TW;
     geo.tiles_y = (p.OH + C::TH - 1) / C::TH;
@@ -712,7 +748,7 @@ int launch_x6_t(const ConvParams& p, hipStream_t stream) {
     const int cus = OCC * device_cus();
     int grid = (int)(nitems < cus ? nitems : cus);
     if (grid > geo.ctiles) grid -= grid % geo.ctiles;   // grid stride keeps the cout slice of a workgroup constant
-    auto kern = conv_x6_kernel<KS, S, CT, NR, NW, OCC>;
+    auto kern = conv_x6_kernel<KS, S, CT, NR, NW, OCC, NBUF>;
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), C::LDS)) return e_;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), C::LDS, stream, p, geo);
     return (int)hipGetLastError();
@@ -755,11 +791,11 @@ static int x6_variant(const ConvParams& p, int k, int stride) {
 #define X6_MODE 2
 #endif
 #if X6_MODE == 1
-#define X6_KARGS(KS_, S_, CT_, NR1_) KS_, S_, CT_, (NR1_) / 2, 8, 1
+#define X6_KARGS(KS_, S_, CT_, NR1_) KS_, S_, CT_, (NR1_) / 2, 8, 1, 2
 #elif X6_MODE == 2
-#define X6_KARGS(KS_, S_, CT_, NR1_) KS_, S_, CT_, ((S_) == 2 ? (NR1_) / 2 : ((NR1_) > 8 ? 8 : (NR1_) == 8 && (CT_) == 2 ? 4 : (NR1_))), 4, 2
+#define X6_KARGS(KS_, S_, CT_, NR1_) KS_, S_, CT_, ((S_) == 2 ? (X6_S2_SINGLE ? (NR1_) : (NR1_) / 2) : ((NR1_) > 8 ? 8 : (NR1_) == 8 && (CT_) == 2 ? 4 : (NR1_))), 4, 2, ((S_) == 2 ? X6_S2_NBUF : 2)
 #else
-#define X6_KARGS(KS_, S_, CT_, NR1_) KS_, S_, CT_, NR1_, 4, 1
+#define X6_KARGS(KS_, S_, CT_, NR1_) KS_, S_, CT_, NR1_, 4, 1, 2
 #endif
 int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream) {
     if (!conv_x6_supported(p, k, stride)) return (int)hipErrorInvalidValue;
@@ -946,7 +982,7 @@ void pack_stem_w1_x6(const float* w, const float* b, float* dst) {
 
 int launch_stem_fused_x6(const StemFusedParams& sp, hipStream_t stream) {
     if (!stem_fused_x6_supported(sp.cin, sp.Cmid, sp.Coutp)) return (int)hipErrorInvalidValue;
-    using C = X6Cfg<3, 2, 4, 2, 4>;
+    using C = X6Cfg<3, 2, 4, X6_STEM_NR, 4, X6_STEM_NBUF>;
     ConvParams p{};
     p.x = nullptr; p.y = sp.y; p.res = nullptr; p.w = sp.w2; p.bias = sp.bias2;
     p.N = sp.N; p.H = sp.H; p.W = sp.W; p.OH = sp.OH; p.OW = sp.OW; p.Cinp = sp.Cmid; p.Coutp = sp.Coutp; p.relu = 1; p.fmt = FMT_F32;
@@ -1042,17 +1078,18 @@ int launch_conv_x6_jobs(const ConvParams* ps, int n, int k, int stride, hipStrea
 const char* conv_x6_kernel_name(const ConvParams& p, int k, int stride) {
     // as rocprofv3 prints the instantiations of launch_conv_x6 (X6_KARGS evaluated), by x6_variant
 #if X6_MODE == 2
-    static const char* const n3[] = {"conv_x6_kernel<3, 2, 4, 2, 4, 2>", "conv_x6_kernel<3, 2, 2, 1, 4, 2>", "conv_x6_kernel<3, 1, 4, 8, 4, 2>",
-                                     "conv_x6_kernel<3, 1, 4, 8, 4, 2>", "conv_x6_kernel<3, 1, 2, 4, 4, 2>"};
-    static const char* const n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 8, 4, 2>", "conv_x6_kernel<1, 1, 4, 8, 4, 2>", "conv_x6_kernel<1, 1, 2, 4, 4, 2>"};
+    static const char* const n3[] = {X6_S2_SINGLE ? "conv_x6_kernel<3, 2, 4, 4, 4, 2, 1>" : "conv_x6_kernel<3, 2, 4, 2, 4, 2, 2>",
+                                     X6_S2_SINGLE ? "conv_x6_kernel<3, 2, 2, 2, 4, 2, 1>" : "conv_x6_kernel<3, 2, 2, 1, 4, 2, 2>",
+                                     "conv_x6_kernel<3, 1, 4, 8, 4, 2, 2>", "conv_x6_kernel<3, 1, 4, 8, 4, 2, 2>", "conv_x6_kernel<3, 1, 2, 4, 4, 2, 2>"};
+    static const char* const n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 8, 4, 2, 2>", "conv_x6_kernel<1, 1, 4, 8, 4, 2, 2>", "conv_x6_kernel<1, 1, 2, 4, 4, 2, 2>"};
 #elif X6_MODE == 1
-    static const char* const n3[] = {"conv_x6_kernel<3, 2, 4, 2, 8, 1>", "conv_x6_kernel<3, 2, 2, 1, 8, 1>", "conv_x6_kernel<3, 1, 4, 4, 8, 1>",
-                                     "conv_x6_kernel<3, 1, 4, 8, 8, 1>", "conv_x6_kernel<3, 1, 2, 4, 8, 1>"};
-    static const char* const n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 4, 8, 1>", "conv_x6_kernel<1, 1, 4, 8, 8, 1>", "conv_x6_kernel<1, 1, 2, 4, 8, 1>"};
+    static const char* const n3[] = {"conv_x6_kernel<3, 2, 4, 2, 8, 1, 2>", "conv_x6_kernel<3, 2, 2, 1, 8, 1, 2>", "conv_x6_kernel<3, 1, 4, 4, 8, 1, 2>",
+                                     "conv_x6_kernel<3, 1, 4, 8, 8, 1, 2>", "conv_x6_kernel<3, 1, 2, 4, 8, 1, 2>"};
+    static const char* const n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 4, 8, 1, 2>", "conv_x6_kernel<1, 1, 4, 8, 8, 1, 2>", "conv_x6_kernel<1, 1, 2, 4, 8, 1, 2>"};
 #else
-    static const char* const n3[] = {"conv_x6_kernel<3, 2, 4, 4, 4, 1>", "conv_x6_kernel<3, 2, 2, 2, 4, 1>", "conv_x6_kernel<3, 1, 4, 8, 4, 1>",
-                                     "conv_x6_kernel<3, 1, 4, 16, 4, 1>", "conv_x6_kernel<3, 1, 2, 8, 4, 1>"};
-    static const char* const n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 8, 4, 1>", "conv_x6_kernel<1, 1, 4, 16, 4, 1>", "conv_x6_kernel<1, 1, 2, 8, 4, 1>"};
+    static const char* const n3[] = {"conv_x6_kernel<3, 2, 4, 4, 4, 1, 2>", "conv_x6_kernel<3, 2, 2, 2, 4, 1, 2>", "conv_x6_kernel<3, 1, 4, 8, 4, 1, 2>",
+                                     "conv_x6_kernel<3, 1, 4, 16, 4, 1, 2>", "conv_x6_kernel<3, 1, 2, 8, 4, 1, 2>"};
+    static const char* const n1[] = {"", "", "conv_x6_kernel<1, 1, 4, 8, 4, 1, 2>", "conv_x6_kernel<1, 1, 4, 16, 4, 1, 2>", "conv_x6_kernel<1, 1, 2, 8, 4, 1, 2>"};
 #endif
     if (k == 1 && conv1x1_x6_supported(p)) return "conv1x1_x6_kernel";
     const int v = x6_variant(p, k, stride);

@@ -260,6 +260,249 @@ __global__ __launch_bounds__(HTHREADS, 2) void head_x6_kernel(HeadParams p, int 
     }
 }
 
+// ---- second form: exact 2x / 4x / 8x grids (the network's own: branch b lives on H >> (b + 1)) ---------------------------
+// One workgroup = 16x16 pixels = 4 waves; a lane owns a 2x2 pixel BLOCK (and, as before, 4 + 4 channels of the chunk):
+// the four pixels of a block share their bilinear sources — 3x3 pixels of the 2x branch, 2x2 of the 4x and 8x branches,
+// 17 LDS reads per 16 channels where one pixel per lane takes 12 each — and the W0 / W3 fragments read from LDS feed four
+// 16-pixel MFMA column groups (group j = pixel (j & 1, j >> 1) of every block).  2.8x fewer LDS reads per pixel than the
+// first form, which the LDS pipe bounds (33 ds_read_b128 per 16 pixels and chunk).  The interpolation is separable
+// (v0 + l (v1 - v0) along x, then y: exact where the clamped border duplicates a source); sources beyond the grid are
+// clamped while STAGING, so a lane's taps need no border cases.
+constexpr int V2_SIDE0 = 10, V2_SIDE1 = 6, V2_SIDE2 = 4;                 // source-region sides of a 16x16 tile
+constexpr int V2_PIX = V2_SIDE0 * V2_SIDE0 + V2_SIDE1 * V2_SIDE1 + V2_SIDE2 * V2_SIDE2;     // 152
+constexpr int V2_BUF = 160 * PIXB;                                       // 5 staging rows of 32 pixels (152 used): 23040 B
+constexpr int V2_THREADS = 256;
+
+template <int NCH0, int M3>
+__global__ __launch_bounds__(V2_THREADS, 2) void head_x6_v2_kernel(HeadParams p, int tiles_x, int tiles_y) {
+    constexpr int WFR = 2 * NCH0 * 3 + M3 * 3;
+    constexpr int WBYTES = WFR * 1024;
+    constexpr int STRIDE = V2_BUF + WBYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pxl = lane & 15, q = lane >> 4;
+    int b_ = blockIdx.x;
+    const int tx = b_ % tiles_x; b_ /= tiles_x;
+    const int ty = b_ % tiles_y;
+    const int n = b_ / tiles_y;
+    const int oy0 = ty * 16, ox0 = tx * 16;
+    const int nchunks = p.Ctp >> 5;
+    constexpr int side[3] = {V2_SIDE0, V2_SIDE1, V2_SIDE2};
+    constexpr int rbase[3] = {0, V2_SIDE0 * V2_SIDE0, V2_SIDE0 * V2_SIDE0 + V2_SIDE1 * V2_SIDE1};
+
+    // ---- staging map: unit u = it*256 + tid -> staged pixel u >> 3, 16-byte piece u & 7 (sources clamped into the grid;
+    // the 8 slots past the last region re-load its last pixel: every load and LDS write of the loop is unconditional)
+    constexpr int SIT = (V2_PIX * 8 + V2_THREADS - 1) / V2_THREADS;       // 5
+    uint32_t so[SIT];               // byte offset inside the unit's tensor t[b]
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+        const int s_ = min(it * (V2_THREADS / 8) + (tid >> 3), V2_PIX - 1);
+        const int b = s_ >= rbase[2] ? 2 : (s_ >= rbase[1] ? 1 : 0);
+        const int sd = b == 2 ? V2_SIDE2 : (b == 1 ? V2_SIDE1 : V2_SIDE0);
+        const int r = s_ - (b == 2 ? rbase[2] : (b == 1 ? rbase[1] : 0));
+        const int yy = min(max((oy0 >> (b + 1)) - 1 + r / sd, 0), p.th[b] - 1);
+        const int xx = min(max((ox0 >> (b + 1)) - 1 + r % sd, 0), p.tw[b] - 1);
+        so[it] = (uint32_t)(((n * p.th[b] + yy) * p.tw[b] + xx) * (p.Ctp * 4) + (tid & 7) * 16);
+    }
+    const int lane_lds = (tid >> 3) * PIXB + (tid & 7) * 16;
+    constexpr int WIT = (WFR * 64 + V2_THREADS - 1) / V2_THREADS;
+    uint4 sr[SIT], wreg[WIT];
+    // (rows 0..2 of the map are the 2x branch's; row 3 holds its last 4 pixels, then the 4x branch's; row 4 the 4x branch's
+    // last 8, then the 8x branch's)
+#define HEAD_PREFETCH(CH)                                                                     \
+    {                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < SIT; ++it) {                                  \
+            const int s_ = it * (V2_THREADS / 8) + (tid >> 3);                                \
+            const char* base = it < 3 ? p.t[0] : it == 3 ? (s_ < rbase[1] ? p.t[0] : p.t[1]) : (s_ < rbase[2] ? p.t[1] : p.t[2]); \
+            sr[it] = *reinterpret_cast<const uint4*>(base + so[it] + (CH) * 128);             \
+        }                                                                                     \
+        _Pragma("unroll") for (int wi = 0; wi < WIT; ++wi) {                                  \
+            const int wf = min(wi * (V2_THREADS / 64) + (tid >> 6), WFR - 1);                 \
+            const uint4* src = wf < 6 * NCH0                                                  \
+                ? p.w0 + ((size_t)(CH) * 6 * NCH0 + wf) * 64 + lane                           \
+                : p.w3 + ((size_t)(((wf - 6 * NCH0) / 3) * nchunks + (CH)) * 3 + ((wf - 6 * NCH0) % 3)) * 64 + lane; \
+            wreg[wi] = *src;                                                                  \
+        }                                                                                     \
+    }
+#define HEAD_COMMIT(BUF)                                                                      \
+    {                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < SIT; ++it)                                    \
+            *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + it * (V2_THREADS / 8) * PIXB + lane_lds) = sr[it]; \
+        _Pragma("unroll") for (int wi = 0; wi < WIT; ++wi)                                    \
+            if (wi * (V2_THREADS / 64) + (tid >> 6) < WFR)                                    \
+                *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + V2_BUF + (wi * V2_THREADS + tid) * 16) = wreg[wi]; \
+    }
+
+    // ---- this lane's block: pixels (X + dx, Y + dy), group j = dy*2 + dx ----------------------
+    const int bx = pxl & 7, by = pxl >> 3;
+    const int X = ox0 + 2 * bx, Y = oy0 + 4 * wave + 2 * by;
+    bf16x8 xf[4][NCH0][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ox = X + (j & 1), oy = Y + (j >> 1);
+        const bool in = ox < p.W && oy < p.H;
+#pragma unroll
+        for (int c = 0; c < NCH0; ++c) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (in) {
+                const float* a = reinterpret_cast<const float*>(p.x0) + (((size_t)n * p.H + oy) * p.W + ox) * (size_t)p.C0p + c * 32 + q * 4;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(a), hi = *reinterpret_cast<const f32x4*>(a + 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] = lo[i]; v[4 + i] = hi[i]; }
+            }
+            x6_split8(v, xf[j][c]);
+        }
+    }
+    // bilinear geometry (align_corners=False, scale exactly 2^-(b+1)): src = (dst + 0.5) / s - 0.5 = (2 dst + 1 - s) / 2s
+    int toff[3];                    // LDS byte offset of the block's first source pixel (+ q*16)
+    float lx0[3], ly0[3];           // weight of the second tap of pixel dx = 0 / dy = 0; the other pixel's: + 1/s (2x branch: 0.25
+                                    // against the next source pair)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int sh = b + 2;       // log2(2s)
+        const int ny = 2 * Y + 1 - (2 << b), nx = 2 * X + 1 - (2 << b);
+        const int yb = ny >> sh, xb = nx >> sh;     // floor (arithmetic shift); the dy = 1 / dx = 1 pixel: + (b == 0 ? 1 : 0)
+        const float inv = 1.f / (float)(1 << sh);
+        ly0[b] = (float)(ny - (yb << sh)) * inv;
+        lx0[b] = (float)(nx - (xb << sh)) * inv;
+        const int lr = yb - ((oy0 >> (b + 1)) - 1), lc = xb - ((ox0 >> (b + 1)) - 1);
+        toff[b] = (rbase[b] + lr * side[b] + lc) * PIXB + q * 16;
+    }
+
+    f32x4 acc3[4][M3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < M3; ++m) acc3[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    HEAD_PREFETCH(0)
+    HEAD_COMMIT(0)
+    __syncthreads();
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const int buf = cc & 1;
+        HEAD_PREFETCH(min(cc + 1, nchunks - 1))       // (the last iteration re-loads its own chunk: no branch around loads)
+        const char* tb = smem + buf * STRIDE;
+        const char* wb = tb + V2_BUF + lane * 16;
+        float v[4][8];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias0 + cc * 32 + m * 16 + q * 4);
+            f32x4 a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NCH0; ++c) {
+                bf16x8 wa[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) wa[t] = *reinterpret_cast<const bf16x8*>(wb + ((m * NCH0 + c) * 3 + t) * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = x6_mma(wa, xf[j][c], a[j]);
+            }
+            // up-sampled terms of the block's four pixels, 4 channels (m*16 + 4q ..)
+            f32x4 s[4];
+            {       // 2x branch: 3x3 sources; pixel (dx, dy) takes columns dx, dx+1 and rows dy, dy+1
+                const char* t0 = tb + toff[0] + m * 64;
+                f32x4 h[3][2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(t0 + (r * V2_SIDE0) * PIXB);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(t0 + (r * V2_SIDE0 + 1) * PIXB);
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(t0 + (r * V2_SIDE0 + 2) * PIXB);
+                    h[r][0] = v0 + 0.75f * (v1 - v0);         // (X and Y are even: the 2x branch's weights are constants)
+                    h[r][1] = v1 + 0.25f * (v2 - v1);
+                }
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    s[dx] = h[0][dx] + 0.75f * (h[1][dx] - h[0][dx]);
+                    s[2 + dx] = h[1][dx] + 0.25f * (h[2][dx] - h[1][dx]);
+                }
+            }
+#pragma unroll
+            for (int b = 1; b < 3; ++b) {       // 4x / 8x branches: the block's pixels share one 2x2 source cell
+                const char* t0 = tb + toff[b] + m * 64;
+                const int sd = b == 1 ? V2_SIDE1 : V2_SIDE2;
+                const float step = b == 1 ? 0.25f : 0.125f;         // 1/s: the weight step between the block's two pixels
+                f32x4 h[2][2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(t0 + (r * sd) * PIXB);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(t0 + (r * sd + 1) * PIXB);
+                    const f32x4 d = v1 - v0;
+                    h[r][0] = v0 + lx0[b] * d;
+                    h[r][1] = h[r][0] + step * d;
+                }
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const f32x4 d = h[1][dx] - h[0][dx];
+                    const f32x4 o0 = h[0][dx] + ly0[b] * d;
+                    s[dx] += o0;
+                    s[2 + dx] += o0 + step * d;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[j][m * 4 + i] = relu1((a[j][i] + bias[i]) + s[j][i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x8 hf[3];
+            x6_split8(v[j], hf);
+#pragma unroll
+            for (int m = 0; m < M3; ++m) {
+                bf16x8 w3[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) w3[t] = *reinterpret_cast<const bf16x8*>(wb + (6 * NCH0 + m * 3 + t) * 1024);
+                acc3[j][m] += x6_mma(w3, hf, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+        }
+        HEAD_COMMIT(buf ^ 1)
+        __syncthreads();
+    }
+#undef HEAD_PREFETCH
+#undef HEAD_COMMIT
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ox = X + (j & 1), oy = Y + (j >> 1);
+        if (ox < p.W && oy < p.H) {
+            float* o = reinterpret_cast<float*>(p.y) + (((size_t)n * p.H + oy) * p.W + ox) * (size_t)p.C3p;
+#pragma unroll
+            for (int m = 0; m < M3; ++m) {
+                const int co = m * 16 + q * 4;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias3 + co);
+                f32x4 r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = relu1(acc3[j][m][i] + bv[i]);
+                *reinterpret_cast<f32x4*>(o + co) = r;
+            }
+            for (int c = M3 * 16 + q * 4; c < p.C3p; c += 16)
+                *reinterpret_cast<f32x4*>(o + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+template <int NCH0, int M3>
+int launch_head_x6_v2_t(const HeadParams& p, hipStream_t stream) {
+    auto kern = head_x6_v2_kernel<NCH0, M3>;
+    const int lds = 2 * (V2_BUF + (2 * NCH0 * 3 + M3 * 3) * 1024);
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
+    const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 15) / 16;
+    const long long nblk = (long long)p.N * tiles_x * tiles_y;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(V2_THREADS), lds, stream, p, tiles_x, tiles_y);
+    return (int)hipGetLastError();
+}
+
+// the second form's grids: branch b at exactly H >> (b + 1) x W >> (b + 1)
+bool head_x6_exact_grids(const HeadParams& p) {
+    for (int b = 0; b < 3; ++b) {
+        if ((p.th[b] << (b + 1)) != p.H || (p.tw[b] << (b + 1)) != p.W) return false;
+        if ((long long)p.N * p.th[b] * p.tw[b] * p.Ctp * 4 >= 0x7fffffffLL) return false;      // 32-bit staging offsets
+    }
+    return true;
+}
+
 template <int NCH0, int M3>
 int launch_head_x6_t(const HeadParams& p, hipStream_t stream) {
     auto kern = head_x6_kernel<NCH0, M3>;
@@ -310,6 +553,10 @@ int launch_head_x6(const HeadParams& p, hipStream_t stream) {
     if (p.Ctp & 31) return (int)hipErrorInvalidValue;
     const int m3 = p.K <= 16 ? 1 : 2;
     if (p.C3p < 16 * m3 || (p.C3p & 15)) return (int)hipErrorInvalidValue;
+    if (head_x6_exact_grids(p)) {
+        if (p.C0p == 32 && m3 == 1) return launch_head_x6_v2_t<1, 1>(p, stream);
+        if (p.C0p == 32 && m3 == 2) return launch_head_x6_v2_t<1, 2>(p, stream);
+    }
     if (p.C0p == 32 && m3 == 1) return launch_head_x6_t<1, 1>(p, stream);
     if (p.C0p == 32 && m3 == 2) return launch_head_x6_t<1, 2>(p, stream);
     if (p.C0p == 64 && m3 == 1) return launch_head_x6_t<2, 1>(p, stream);
