@@ -18,6 +18,8 @@
 //       FRESH accumulator, added to acc3 by one VALU add per chunk (tools/ubench/x6_numerics.hip: the rounding of a
 //       long MFMA chain is what separates a bf16x6 sum from a blocked f32 sum);
 // h0 never leaves the register file.  In the op-by-op plan these tensors cost 4 GB of HBM traffic per batch-32 step.
+#include <type_traits>
+
 #include "devstate.h"
 #include "kernels.h"
 #include "sb.h"
@@ -272,11 +274,20 @@ constexpr int V2_SIDE0 = 10, V2_SIDE1 = 6, V2_SIDE2 = 4;                 // sour
 constexpr int V2_PIX = V2_SIDE0 * V2_SIDE0 + V2_SIDE1 * V2_SIDE1 + V2_SIDE2 * V2_SIDE2;     // 152
 constexpr int V2_BUF = 160 * PIXB;                                       // 5 staging rows of 32 pixels (152 used): 23040 B
 constexpr int V2_THREADS = 256;
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E) (arrays indexed by a run-time loop counter next
+// to a sched_barrier stay in scratch memory)
+template <int B, int E, class F>
+__device__ __forceinline__ void hx_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        hx_static_for<B + 1, E>(f);
+    }
+}
 
 template <int NCH0, int M3>
 __global__ __launch_bounds__(V2_THREADS, 2) void head_x6_v2_kernel(HeadParams p, int tiles_x, int tiles_y) {
     constexpr int WFR = 2 * NCH0 * 3 + M3 * 3;
-    constexpr int WBYTES = WFR * 1024;
+    constexpr int WBYTES = ((WFR + 3) & ~3) * 1024;     // (whole rows of 4 fragments: the staging writes are unconditional)
     constexpr int STRIDE = V2_BUF + WBYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -306,32 +317,44 @@ __global__ __launch_bounds__(V2_THREADS, 2) void head_x6_v2_kernel(HeadParams p,
     }
     const int lane_lds = (tid >> 3) * PIXB + (tid & 7) * 16;
     constexpr int WIT = (WFR * 64 + V2_THREADS - 1) / V2_THREADS;
-    uint4 sr[SIT], wreg[WIT];
-    // (rows 0..2 of the map are the 2x branch's; row 3 holds its last 4 pixels, then the 4x branch's; row 4 the 4x branch's
-    // last 8, then the 8x branch's)
-#define HEAD_PREFETCH(CH)                                                                     \
-    {                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < SIT; ++it) {                                  \
-            const int s_ = it * (V2_THREADS / 8) + (tid >> 3);                                \
-            const char* base = it < 3 ? p.t[0] : it == 3 ? (s_ < rbase[1] ? p.t[0] : p.t[1]) : (s_ < rbase[2] ? p.t[1] : p.t[2]); \
-            sr[it] = *reinterpret_cast<const uint4*>(base + so[it] + (CH) * 128);             \
-        }                                                                                     \
-        _Pragma("unroll") for (int wi = 0; wi < WIT; ++wi) {                                  \
-            const int wf = min(wi * (V2_THREADS / 64) + (tid >> 6), WFR - 1);                 \
-            const uint4* src = wf < 6 * NCH0                                                  \
-                ? p.w0 + ((size_t)(CH) * 6 * NCH0 + wf) * 64 + lane                           \
-                : p.w3 + ((size_t)(((wf - 6 * NCH0) / 3) * nchunks + (CH)) * 3 + ((wf - 6 * NCH0) % 3)) * 64 + lane; \
-            wreg[wi] = *src;                                                                  \
-        }                                                                                     \
-    }
-#define HEAD_COMMIT(BUF)                                                                      \
-    {                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < SIT; ++it)                                    \
-            *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + it * (V2_THREADS / 8) * PIXB + lane_lds) = sr[it]; \
-        _Pragma("unroll") for (int wi = 0; wi < WIT; ++wi)                                    \
-            if (wi * (V2_THREADS / 64) + (tid >> 6) < WFR)                                    \
-                *reinterpret_cast<uint4*>(smem + (BUF) * STRIDE + V2_BUF + (wi * V2_THREADS + tid) * 16) = wreg[wi]; \
-    }
+    // The next chunk's tiles and weights travel through registers in TWO halves (units [0, UH) at the start of the
+    // iteration, [UH, NU) in its middle; unit u < SIT: tile row u, else weight row u - SIT), each written to the other LDS
+    // buffer — which nobody reads during this iteration — before the next is loaded: 16 registers in flight, not 32.
+    // (rows 0..2 of the tile map are the 2x branch's; row 3 holds its last 4 pixels, then the 4x branch's; row 4 the 4x
+    // branch's last 8, then the 8x branch's)
+    constexpr int NU = SIT + WIT, UH = (NU + 1) / 2;
+    u32x4 sr[UH];
+    auto prefetch = [&](int ch, auto half_c) __attribute__((always_inline)) {
+        constexpr int u0 = decltype(half_c)::value * UH;
+        hx_static_for<u0, (u0 + UH < NU ? u0 + UH : NU)>([&](auto u_c) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_c)::value;
+            if constexpr (u < SIT) {
+                const int s_ = u * (V2_THREADS / 8) + (tid >> 3);
+                const char* base = u < 3 ? p.t[0] : u == 3 ? (s_ < rbase[1] ? p.t[0] : p.t[1]) : (s_ < rbase[2] ? p.t[1] : p.t[2]);
+                sr[u - u0] = *reinterpret_cast<const u32x4*>(base + so[u < SIT ? u : 0] + ch * 128);
+            } else {
+                const int wf = min((u - SIT) * (V2_THREADS / 64) + (tid >> 6), WFR - 1);
+                const uint4* src = wf < 6 * NCH0
+                    ? p.w0 + ((size_t)ch * 6 * NCH0 + wf) * 64 + lane
+                    : p.w3 + ((size_t)(((wf - 6 * NCH0) / 3) * nchunks + ch) * 3 + ((wf - 6 * NCH0) % 3)) * 64 + lane;
+                sr[u - u0] = *reinterpret_cast<const u32x4*>(src);
+            }
+        });
+    };
+    auto commit = [&](int buf, auto half_c) __attribute__((always_inline)) {
+        constexpr int u0 = decltype(half_c)::value * UH;
+        hx_static_for<u0, (u0 + UH < NU ? u0 + UH : NU)>([&](auto u_c) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_c)::value;
+            if constexpr (u < SIT)
+                *reinterpret_cast<u32x4*>(smem + buf * STRIDE + u * (V2_THREADS / 8) * PIXB + lane_lds) = sr[u - u0];
+            else
+                *reinterpret_cast<u32x4*>(smem + buf * STRIDE + V2_BUF + ((u - SIT) * V2_THREADS + tid) * 16) = sr[u - u0];
+        });
+    };
+    constexpr auto HA = std::integral_constant<int, 0>{};
+    constexpr auto HB = std::integral_constant<int, 1>{};
+    float* const bias_s = reinterpret_cast<float*>(smem + 2 * STRIDE);      // bias0, whole (published by the first barrier)
+    for (int i = tid; i < p.Ctp; i += V2_THREADS) bias_s[i] = p.bias0[i];
 
     // ---- this lane's block: pixels (X + dx, Y + dy), group j = dy*2 + dx ----------------------
     const int bx = pxl & 7, by = pxl >> 3;
@@ -375,18 +398,28 @@ __global__ __launch_bounds__(V2_THREADS, 2) void head_x6_v2_kernel(HeadParams p,
 #pragma unroll
         for (int m = 0; m < M3; ++m) acc3[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    HEAD_PREFETCH(0)
-    HEAD_COMMIT(0)
+    prefetch(0, HA);
+    commit(0, HA);
+    prefetch(0, HB);
+    commit(0, HB);
     __syncthreads();
     for (int cc = 0; cc < nchunks; ++cc) {
         const int buf = cc & 1;
-        HEAD_PREFETCH(min(cc + 1, nchunks - 1))       // (the last iteration re-loads its own chunk: no branch around loads)
+        const int nc = min(cc + 1, nchunks - 1);      // (the last iteration re-loads its own chunk: no branch around loads)
+        prefetch(nc, HA);
+        __builtin_amdgcn_sched_barrier(0);            // (left alone, hipcc sinks every load to the LDS write that consumes it)
         const char* tb = smem + buf * STRIDE;
         const char* wb = tb + V2_BUF + lane * 16;
         float v[4][8];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias0 + cc * 32 + m * 16 + q * 4);
+            if (m == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                commit(buf ^ 1, HA);
+                prefetch(nc, HB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_s + cc * 32 + m * 16 + q * 4);
             f32x4 a[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -456,11 +489,10 @@ __global__ __launch_bounds__(V2_THREADS, 2) void head_x6_v2_kernel(HeadParams p,
                 acc3[j][m] += x6_mma(w3, hf, f32x4{0.f, 0.f, 0.f, 0.f});
             }
         }
-        HEAD_COMMIT(buf ^ 1)
+        __builtin_amdgcn_sched_barrier(0);
+        commit(buf ^ 1, HB);
         __syncthreads();
     }
-#undef HEAD_PREFETCH
-#undef HEAD_COMMIT
 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -485,7 +517,7 @@ __global__ __launch_bounds__(V2_THREADS, 2) void head_x6_v2_kernel(HeadParams p,
 template <int NCH0, int M3>
 int launch_head_x6_v2_t(const HeadParams& p, hipStream_t stream) {
     auto kern = head_x6_v2_kernel<NCH0, M3>;
-    const int lds = 2 * (V2_BUF + (2 * NCH0 * 3 + M3 * 3) * 1024);
+    const int lds = 2 * (V2_BUF + ((2 * NCH0 * 3 + M3 * 3 + 3) & ~3) * 1024) + p.Ctp * 4;
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
     const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 15) / 16;
     const long long nblk = (long long)p.N * tiles_x * tiles_y;
