@@ -1,4 +1,5 @@
-// cbam.hip — the CBAM attention of the seg_hrnet3 variant on SB tensors.
+// cbam.hip — the CBAM attention of the seg_hrnet3 variant on SB tensors — and on the
+// fp32-grade mode's plain f32 NHWC tensors: 8 channels are 32 bytes in both (sb.h: load8_fmt / store8_fmt).
 //
 // Replaces ChannelAttention / SpatialAttention of models/seg_hrnet3.py:32-61 and their use inside
 // BasicBlock.forward (:90-91: out = ca(out)*out; out = sa(out)*out, before the residual add) and on
@@ -21,7 +22,7 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v
 
 // ---- pool_partial: grid (P, N), 256 threads; thread = (pixel lane pl, channel group c8) ----------
 __device__ __forceinline__ void pool_partial_body(const char* x, float* partial, int HW, int Cp, int P, int slab, int n,
-                                                  float* ssum, float* smax) {
+                                                  float* ssum, float* smax, bool f32) {
     const int G = Cp >> 3, PL = 256 / G;
     const int S = (HW + P - 1) / P;
     const int p0 = slab * S, p1 = min(HW, p0 + S);
@@ -33,7 +34,7 @@ __device__ __forceinline__ void pool_partial_body(const char* x, float* partial,
         for (int p = p0 + pl; p < p1; p += PL) {
             const char* a = x + ((size_t)n * HW + p) * (size_t)(Cp * 4) + c8 * 32;
             float v[8];
-            join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+            load8_fmt(a, v, f32);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { s[i] += v[i]; m[i] = fmaxf(m[i], v[i]); }
         }
@@ -48,10 +49,10 @@ __device__ __forceinline__ void pool_partial_body(const char* x, float* partial,
         o[0] = a; o[1] = b;
     }
 }
-__global__ __launch_bounds__(256) void pool_partial_kernel(const char* x, float* partial, int HW, int Cp, int P) {
+__global__ __launch_bounds__(256) void pool_partial_kernel(const char* x, float* partial, int HW, int Cp, int P, int f32) {
     __shared__ float ssum[256 * 8];
     __shared__ float smax[256 * 8];
-    pool_partial_body(x, partial, HW, Cp, P, (int)blockIdx.x, (int)blockIdx.y, ssum, smax);
+    pool_partial_body(x, partial, HW, Cp, P, (int)blockIdx.x, (int)blockIdx.y, ssum, smax, f32 != 0);
 }
 
 // ---- ca_mlp: grid N, 256 threads ----------------------------------------------------------------------
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void ca_mlp_kernel(const float* partial, const
 // ---- cbam_maps: thread = (pixel, 8-channel group), group fastest -> coalesced 32-B pieces; the G
 // partial (sum, max) of a pixel meet in LDS ------------------------------------------------------------
 __device__ __forceinline__ void cbam_maps_body(const char* x, const float* ca, float* maps, long long npix, int HW, int C, int Cp,
-                                               long long block, float* ps, float* pm) {
+                                               long long block, float* ps, float* pm, bool f32) {
     const int G = Cp >> 3, PPB = 256 / G;                 // pixels per block
     const int tid = threadIdx.x, pl = tid / G, c8 = tid - pl * G;
     const long long pix = block * PPB + pl;
@@ -116,7 +117,7 @@ __device__ __forceinline__ void cbam_maps_body(const char* x, const float* ca, f
         const float* cn = ca + (size_t)n * Cp + c8 * 8;
         const char* a = x + (size_t)pix * (size_t)(Cp * 4) + c8 * 32;
         float v[8];
-        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+        load8_fmt(a, v, f32);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (c8 * 8 + i < C) { const float u = v[i] * cn[i]; s += u; m = fmaxf(m, u); }
@@ -131,9 +132,9 @@ __device__ __forceinline__ void cbam_maps_body(const char* x, const float* ca, f
     }
 }
 __global__ __launch_bounds__(256) void cbam_maps_kernel(const char* x, const float* ca, float* maps, long long npix,
-                                                        int HW, int C, int Cp) {
+                                                        int HW, int C, int Cp, int f32) {
     __shared__ float ps[256], pm[256];
-    cbam_maps_body(x, ca, maps, npix, HW, C, Cp, (long long)blockIdx.x, ps, pm);
+    cbam_maps_body(x, ca, maps, npix, HW, C, Cp, (long long)blockIdx.x, ps, pm, f32 != 0);
 }
 
 // ---- cbam_apply: thread = (pixel, 8-channel group); the pixel's first thread evaluates the 7x7
@@ -174,15 +175,16 @@ __device__ __forceinline__ void cbam_apply_body(const CbamApplyParams& p, long l
     if (!live) return;
     const float sa = sas[pl];
     const float* cn = p.ca + (size_t)n * p.Cp + c8 * 8;
+    const bool f32 = p.fmt == FMT_F32;
     const char* a = p.x + (size_t)idx * (size_t)(p.Cp * 4) + c8 * 32;
     float v[8];
-    join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+    load8_fmt(a, v, f32);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (sa * cn[i]) * v[i];
     if (p.res) {
         const char* r = p.res + (size_t)idx * (size_t)(p.Cp * 4) + c8 * 32;
         float rv[8];
-        join8(*reinterpret_cast<const uint4*>(r), *reinterpret_cast<const uint4*>(r + 16), rv);
+        load8_fmt(r, rv, f32);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += rv[i];
     }
@@ -190,11 +192,7 @@ __device__ __forceinline__ void cbam_apply_body(const CbamApplyParams& p, long l
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
     }
-    uint4 hi, lo;
-    split8(v, hi, lo);
-    char* o = p.y + (size_t)idx * (size_t)p.y_pix_bytes + ((p.y_c0 >> 3) + c8) * 32;
-    *reinterpret_cast<uint4*>(o) = hi;
-    *reinterpret_cast<uint4*>(o + 16) = lo;
+    store8_fmt(p.y + (size_t)idx * (size_t)p.y_pix_bytes + ((p.y_c0 >> 3) + c8) * 32, v, f32);
 }
 
 __global__ __launch_bounds__(256) void cbam_apply_kernel(CbamApplyParams p, long long npix) {
@@ -218,6 +216,7 @@ __device__ __forceinline__ void cbam_spatial_body(const CbamApplyParams& p, int 
     if (tid < 98) w[tid] = p.w_sa[tid];
     const int G = p.Cp >> 3, PPB = 256 / G;
     const int lg = tid & (G - 1), pl = tid / G;
+    const bool f32 = p.fmt == FMT_F32;
     float cn[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) cn[i] = p.ca[(size_t)n * p.Cp + lg * 8 + i];
@@ -246,7 +245,7 @@ __device__ __forceinline__ void cbam_spatial_body(const CbamApplyParams& p, int 
             float s = 0.f, m = -INFINITY;
             if (inside[k] && lg * 8 < p.C) {
                 float v[8];
-                join8(h4[k], l4[k], v);
+                join8_fmt(h4[k], l4[k], v, f32);
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     if (lg * 8 + i < p.C) { const float u = v[i] * cn[i]; s += u; m = fmaxf(m, u); }
@@ -272,13 +271,13 @@ __device__ __forceinline__ void cbam_spatial_body(const CbamApplyParams& p, int 
         const size_t idx = img + (size_t)Y * p.W + X;
         const char* a = p.x + idx * (size_t)(p.Cp * 4) + lg * 32;
         float v[8];
-        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), v);
+        load8_fmt(a, v, f32);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (sa * cn[i]) * v[i];
         if (p.res) {
             const char* r = p.res + idx * (size_t)(p.Cp * 4) + lg * 32;
             float rv[8];
-            join8(*reinterpret_cast<const uint4*>(r), *reinterpret_cast<const uint4*>(r + 16), rv);
+            load8_fmt(r, rv, f32);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += rv[i];
         }
@@ -286,11 +285,7 @@ __device__ __forceinline__ void cbam_spatial_body(const CbamApplyParams& p, int 
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
         }
-        uint4 hi, lo;
-        split8(v, hi, lo);
-        char* o = p.y + idx * (size_t)p.y_pix_bytes + ((p.y_c0 >> 3) + lg) * 32;
-        *reinterpret_cast<uint4*>(o) = hi;
-        *reinterpret_cast<uint4*>(o + 16) = lo;
+        store8_fmt(p.y + idx * (size_t)p.y_pix_bytes + ((p.y_c0 >> 3) + lg) * 32, v, f32);
     }
 }
 
@@ -314,9 +309,9 @@ __global__ __launch_bounds__(256) void cbam_jobs_kernel(CbamJobs jobs) {
     const CbamJob& q = jobs.j[j];
     const int bid = b - jobs.start[j];
     switch (q.kind) {
-        case CBAM_POOL: pool_partial_body(q.ap.x, q.partial, q.HW, q.ap.Cp, q.P, bid % q.P, bid / q.P, sh, sh + 2048); break;
+        case CBAM_POOL: pool_partial_body(q.ap.x, q.partial, q.HW, q.ap.Cp, q.P, bid % q.P, bid / q.P, sh, sh + 2048, q.ap.fmt == FMT_F32); break;
         case CBAM_MLP: ca_mlp_body(q.partial, q.w0, q.w2, q.ca, q.HW, q.ap.C, q.ap.Cp, q.Cr, q.P, bid, sh, sh + 512, sh + 1024, sh + 1088); break;
-        case CBAM_MAPS: cbam_maps_body(q.ap.x, q.ap.ca, q.maps, (long long)q.ap.N * q.HW, q.HW, q.ap.C, q.ap.Cp, bid, sh, sh + 256); break;
+        case CBAM_MAPS: cbam_maps_body(q.ap.x, q.ap.ca, q.maps, (long long)q.ap.N * q.HW, q.HW, q.ap.C, q.ap.Cp, bid, sh, sh + 256, q.ap.fmt == FMT_F32); break;
         case CBAM_APPLY: cbam_apply_body(q.ap, (long long)q.ap.N * q.HW, bid, sw, sh); break;
         default: cbam_spatial_body(q.ap, q.tiles_x, q.tiles_y, bid, sh, sw); break;
     }
@@ -353,10 +348,8 @@ __global__ __launch_bounds__(256) void resample_slice_kernel(ResampleParams p, l
     const int y = (int)(row % p.H);
     const int n = (int)(row / p.H);
     float v[8];
-    auto ld = [&](size_t sp, float* out) {
-        const char* a = p.x + sp * (size_t)(p.Cp_src * 4) + c8 * 32;
-        join8(*reinterpret_cast<const uint4*>(a), *reinterpret_cast<const uint4*>(a + 16), out);
-    };
+    const bool f32 = p.fmt == FMT_F32;
+    auto ld = [&](size_t sp, float* out) { load8_fmt(p.x + sp * (size_t)(p.Cp_src * 4) + c8 * 32, out, f32); };
     if (p.h == p.H && p.w == p.W) {
         ld((size_t)pix, v);
     } else {
@@ -368,11 +361,7 @@ __global__ __launch_bounds__(256) void resample_slice_kernel(ResampleParams p, l
         for (int i = 0; i < 8; ++i)
             v[i] = ly.l0 * (lx.l0 * v00[i] + lx.l1 * v01[i]) + ly.l1 * (lx.l0 * v10[i] + lx.l1 * v11[i]);
     }
-    uint4 hi, lo;
-    split8(v, hi, lo);
-    char* o = p.y + (size_t)pix * (size_t)p.y_pix_bytes + ((p.y_c0 >> 3) + c8) * 32;
-    *reinterpret_cast<uint4*>(o) = hi;
-    *reinterpret_cast<uint4*>(o + 16) = lo;
+    store8_fmt(p.y + (size_t)pix * (size_t)p.y_pix_bytes + ((p.y_c0 >> 3) + c8) * 32, v, f32);
 }
 
 __global__ __launch_bounds__(256) void zero_slice_kernel(char* y, long long npix, int y_pix_bytes, int c0, int ngroups) {
@@ -389,9 +378,9 @@ inline int blocks(long long total) { return (int)((total + 255) / 256); }
 
 }  // namespace
 
-int launch_pool_partial(const char* x, float* partial, int N, int HW, int Cp, int P, hipStream_t s) {
-    if ((Cp & 7) || Cp > 256 || Cp < 8) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(pool_partial_kernel, dim3(P, N), dim3(256), 0, s, x, partial, HW, Cp, P);
+int launch_pool_partial(const char* x, float* partial, int N, int HW, int Cp, int P, hipStream_t s, int fmt) {
+    if ((Cp & 7) || Cp > 256 || Cp < 8 || (fmt != FMT_SB && fmt != FMT_F32)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pool_partial_kernel, dim3(P, N), dim3(256), 0, s, x, partial, HW, Cp, P, fmt == FMT_F32 ? 1 : 0);
     return (int)hipGetLastError();
 }
 
@@ -402,17 +391,17 @@ int launch_ca_mlp(const float* partial, const float* w0, const float* w2, float*
     return (int)hipGetLastError();
 }
 
-int launch_cbam_maps(const char* x, const float* ca, float* maps, int N, int HW, int C, int Cp, hipStream_t s) {
+int launch_cbam_maps(const char* x, const float* ca, float* maps, int N, int HW, int C, int Cp, hipStream_t s, int fmt) {
     const long long npix = (long long)N * HW;
-    if ((Cp & 7) || Cp > 2048 || Cp < 8) return (int)hipErrorInvalidValue;
+    if ((Cp & 7) || Cp > 2048 || Cp < 8 || (fmt != FMT_SB && fmt != FMT_F32)) return (int)hipErrorInvalidValue;
     const int ppb = 256 / (Cp >> 3);
-    hipLaunchKernelGGL(cbam_maps_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, s, x, ca, maps, npix, HW, C, Cp);
+    hipLaunchKernelGGL(cbam_maps_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, s, x, ca, maps, npix, HW, C, Cp, fmt == FMT_F32 ? 1 : 0);
     return (int)hipGetLastError();
 }
 
 int launch_cbam_apply(const CbamApplyParams& p, hipStream_t s) {
     const long long npix = (long long)p.N * p.H * p.W;
-    if ((p.y_c0 & 7) || (p.Cp & 7) || p.Cp > 2048 || p.Cp < 8) return (int)hipErrorInvalidValue;
+    if ((p.y_c0 & 7) || (p.Cp & 7) || p.Cp > 2048 || p.Cp < 8 || (p.fmt != FMT_SB && p.fmt != FMT_F32)) return (int)hipErrorInvalidValue;
     const int ppb = 256 / (p.Cp >> 3);
     hipLaunchKernelGGL(cbam_apply_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, s, p, npix);
     return (int)hipGetLastError();
@@ -421,7 +410,7 @@ int launch_cbam_apply(const CbamApplyParams& p, hipStream_t s) {
 // workgroups job `q` needs (the grid its own launch would use); -1: invalid
 long long cbam_job_blocks(CbamJob& q) {
     const int Cp = q.ap.Cp;
-    if ((Cp & 7) || Cp < 8) return -1;
+    if ((Cp & 7) || Cp < 8 || (q.ap.fmt != FMT_SB && q.ap.fmt != FMT_F32)) return -1;
     switch (q.kind) {
         case CBAM_POOL: return Cp > 256 ? -1 : (long long)q.P * q.ap.N;
         case CBAM_MLP: return (Cp > 512 || q.Cr > 64 || q.Cr < 1) ? -1 : q.ap.N;
@@ -459,7 +448,7 @@ bool cbam_spatial_supported(int Cp) {
 }
 
 int launch_cbam_spatial(const CbamApplyParams& p, hipStream_t s) {
-    if (!cbam_spatial_supported(p.Cp) || (p.y_c0 & 7) || p.C < 1 || p.C > p.Cp) return (int)hipErrorInvalidValue;
+    if (!cbam_spatial_supported(p.Cp) || (p.y_c0 & 7) || p.C < 1 || p.C > p.Cp || (p.fmt != FMT_SB && p.fmt != FMT_F32)) return (int)hipErrorInvalidValue;
     const int tiles_x = (p.W + CS_TW - 1) / CS_TW, tiles_y = (p.H + CS_TH - 1) / CS_TH;
     const long long nblk = (long long)tiles_x * tiles_y * p.N;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -468,7 +457,7 @@ int launch_cbam_spatial(const CbamApplyParams& p, hipStream_t s) {
 }
 
 int launch_resample_slice(const ResampleParams& p, hipStream_t s) {
-    if ((p.y_c0 & 7) || (p.Cp_src & 7)) return (int)hipErrorInvalidValue;
+    if ((p.y_c0 & 7) || (p.Cp_src & 7) || (p.fmt != FMT_SB && p.fmt != FMT_F32)) return (int)hipErrorInvalidValue;
     const long long total = (long long)p.N * p.H * p.W * ((p.C + 7) >> 3);
     hipLaunchKernelGGL(resample_slice_kernel, dim3(blocks(total)), dim3(256), 0, s, p, total);
     return (int)hipGetLastError();

@@ -826,7 +826,8 @@ int launch_conv_x6(const ConvParams& p, int k, int stride, hipStream_t stream) {
 // a time; the weight fragments of a cout tile (3 * NCH KB) stream through a double-buffered LDS image shared by the four
 // waves.  Per cout tile the 6 * NCH products run as one chain from a fresh accumulator, low-order products first.
 template <int NCH, int PG>
-__device__ __forceinline__ void x6_c1_body(const ConvParams& p, const long long ntiles, const int tiles_per_row, const int bid, const int G) {
+__device__ __forceinline__ void x6_c1_body(const ConvParams& p, const long long ntiles, const int tiles_per_row, const int bid, const int G,
+                                           const int m0, const int m1) {       // cout tiles [m0, m1) of 16
     constexpr int WFR = 3 * NCH;                    // 1-KB weight fragments per 16-cout tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -877,14 +878,13 @@ __device__ __forceinline__ void x6_c1_body(const ConvParams& p, const long long 
         for (int it = 0; it < WIT; ++it)
             if (it * NTHREADS + tid < WFR * 64) *reinterpret_cast<u32x4*>(smem + buf * (WFR * 1024) + (it * NTHREADS + tid) * 16) = wreg[it];
     };
-    const int ntile16 = p.Coutp >> 4;
-    prefetch(0);
+    prefetch(m0);
     commit(0);
     __syncthreads();
     const int rfl = relu_floor(p.relu);
-    for (int m = 0; m < ntile16; ++m) {
-        const int buf = m & 1;
-        if (m + 1 < ntile16) prefetch(m + 1);
+    for (int m = m0; m < m1; ++m) {
+        const int buf = (m - m0) & 1;
+        if (m + 1 < m1) prefetch(m + 1);
         const char* wb = smem + buf * (WFR * 1024) + lane * 16;
         const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + m * 16 + g * 4);
         f32x4 d[PG];
@@ -917,7 +917,7 @@ __device__ __forceinline__ void x6_c1_body(const ConvParams& p, const long long 
             for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(relu_opt(d[pg][k] + bv[k], rfl));
             if (valid[pg]) *reinterpret_cast<u32x4*>(p.y + (pixel[pg] * (size_t)p.Coutp + m * 16 + g * 4) * 4) = o;
         }
-        if (m + 1 < ntile16) {
+        if (m + 1 < m1) {
             commit(buf ^ 1);
             __syncthreads();
         }
@@ -925,8 +925,10 @@ __device__ __forceinline__ void x6_c1_body(const ConvParams& p, const long long 
 }
 
 template <int NCH, int PG>
-__global__ __launch_bounds__(NTHREADS, 2) void conv1x1_x6_kernel(ConvParams p, long long ntiles, int tiles_per_row) {
-    x6_c1_body<NCH, PG>(p, ntiles, tiles_per_row, (int)blockIdx.x, (int)gridDim.x);
+__global__ __launch_bounds__(NTHREADS, 2) void conv1x1_x6_kernel(ConvParams p, long long ntiles, int tiles_per_row, int per) {
+    // blockIdx.y: a slice of `per` cout tiles (wide outputs on small grids: the pixel groups alone do not fill the chip)
+    const int m0 = (int)blockIdx.y * per, ntile16 = p.Coutp >> 4;
+    x6_c1_body<NCH, PG>(p, ntiles, tiles_per_row, (int)blockIdx.x, (int)gridDim.x, m0, m0 + per < ntile16 ? m0 + per : ntile16);
 }
 
 // the fuse-up 1x1 convolutions of an HRModule (models/seg_hrnet.py:176-197) in one launch
@@ -946,9 +948,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1x1_x6_jobs_kernel(X6C1Jobs j
     const int bid = b - jobs.start[j], G = jobs.start[j + 1] - jobs.start[j];
     const ConvParams& p = jobs.p[j];
     switch (p.Cinp >> 5) {
-        case 2: x6_c1_body<2, 1>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G); break;
-        case 4: x6_c1_body<4, 1>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G); break;
-        default: x6_c1_body<8, 1>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G); break;
+        case 2: x6_c1_body<2, 1>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G, 0, p.Coutp >> 4); break;
+        case 4: x6_c1_body<4, 1>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G, 0, p.Coutp >> 4); break;
+        default: x6_c1_body<8, 1>(p, jobs.ntiles[j], jobs.tiles_per_row[j], bid, G, 0, p.Coutp >> 4); break;
     }
 }
 
@@ -959,9 +961,15 @@ int launch_c1_x6_t(const ConvParams& p, hipStream_t stream) {
     const long long ntiles = (long long)p.N * p.H * tiles_per_row;
     const long long nblk = (ntiles + 4 * PG - 1) / (4 * PG);
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    // cout slices: enough workgroups for four per CU, at least four cout tiles each (a slice re-loads and re-splits the input)
+    const int ntile16 = p.Coutp >> 4;
+    long long want = (4LL * device_cus() + nblk - 1) / nblk;
+    if (want > ntile16 / 4) want = ntile16 / 4;
+    const int slices = want < 1 ? 1 : (int)want;
+    const int per = (ntile16 + slices - 1) / slices;
     auto kern = conv1x1_x6_kernel<NCH, PG>;
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTHREADS), lds, stream, p, ntiles, tiles_per_row);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)((ntile16 + per - 1) / per)), dim3(NTHREADS), lds, stream, p, ntiles, tiles_per_row, per);
     return (int)hipGetLastError();
 }
 
@@ -1012,11 +1020,13 @@ int launch_stem_fused_x6(const StemFusedParams& sp, hipStream_t stream) {
 // 1x1 with 64 / 128 / 256 (or 32 / 96 / 192) input channels and no residual: the register-resident form
 bool conv1x1_x6_supported(const ConvParams& p) {
     const int n = p.Cinp / 32;
-    // measured (batch 32): 64 -> 480 on a 64x64 grid 135 -> 85 us, but 128 -> 480 on 32x32 62 -> 72 and 256 -> 480 on 16x16
-    // 31 -> 44 (a workgroup walks all cout tiles serially: small grids want the tile-stream kernel's cout slices side by
-    // side) — so: wide outputs on grids of at least 2048 pixels per image (a rule on the shape, never on the batch)
+    // measured (batch 32) against the tile-stream kernel: 64 -> 480 on a 64x64 grid 135 -> 85 us, 128 -> 480 on 32x32 62 -> 48,
+    // 256 -> 480 on 16x16 30 -> 23 (with the cout range cut into slices, blockIdx.y, where the pixel groups alone leave CUs
+    // idle) — so: every WIDE output (256 couts and more: the head's products; the fuse-up 1x1s of a module stay with the
+    // tile-stream kernel, which also serves their merged launch — a rule on the layer, never on the batch: the two kernels
+    // sum in different orders)
     return p.fmt == FMT_F32 && !p.res && !p.out_f32 && p.nheads <= 1 && (p.Cinp % 32) == 0 && (p.Coutp % 16) == 0 && p.H == p.OH &&
-           p.W == p.OW && (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8) && (long long)p.H * p.W >= 2048 && p.Coutp >= 64 &&
+           p.W == p.OW && (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8) && p.Coutp >= 256 &&
            !getenv("ESAHRNET_X6_NO_C1");
 }
 int launch_conv1x1_x6(const ConvParams& p, hipStream_t stream) {

@@ -187,13 +187,8 @@ __global__ __launch_bounds__(GT_T, 2) void head_gather_kernel(GatherParams p, in
                     acc[4] += sm.l0 * u1.x + sm.l1 * w1.x; acc[5] += sm.l0 * u1.y + sm.l1 * w1.y;
                     acc[6] += sm.l0 * u1.z + sm.l1 * w1.z; acc[7] += sm.l0 * u1.w + sm.l1 * w1.w;
                 }
-            if (Y0 < p.H && X0 < p.W) {
-                uint4 hi, lo;
-                split8(acc, hi, lo);
-                char* o = p.y + (((size_t)n * p.H + Y0) * p.W + X0) * (size_t)(p.Cp * 4) + (size_t)cg * 32;
-                *reinterpret_cast<uint4*>(o) = hi;
-                *reinterpret_cast<uint4*>(o + 16) = lo;
-            }
+            if (Y0 < p.H && X0 < p.W)
+                store8_fmt(p.y + (((size_t)n * p.H + Y0) * p.W + X0) * (size_t)(p.Cp * 4) + (size_t)cg * 32, acc, p.fmt == FMT_F32);
         }
         __syncthreads();        // bs is rewritten by the next x pass; zs now holds the next group
     }
@@ -240,7 +235,7 @@ bool head_gather_supported(int H, int W, const int* h, const int* w, int Cp) {
 }
 
 int launch_head_gather(GatherParams p, hipStream_t stream) {
-    if (!head_gather_supported(p.H, p.W, p.h, p.w, p.Cp)) return (int)hipErrorInvalidValue;
+    if (!head_gather_supported(p.H, p.W, p.h, p.w, p.Cp) || (p.fmt != FMT_SB && p.fmt != FMT_F32)) return (int)hipErrorInvalidValue;
     fill_windows(p);
     p.ngroups = p.Cp >> 3;
     p.nreal = (p.C + 7) >> 3;

@@ -37,6 +37,24 @@ constexpr int RMAY1 = 7, RMAY2 = 5, RMAY3 = 4;    // max source-region height (8
 constexpr int REG_PIX = RMAY1 * RMAX1 + RMAY2 * RMAX2 + RMAY3 * RMAX3;   // 132 pixels
 constexpr int BUF_BYTES = REG_PIX * PIXB;                                // 28080 B per buffer
 
+// a - b on two / four floats as packed instructions (hipcc lowers a vector fsub to one v_sub_f32 per element; the packed
+// add takes the negation as a source modifier)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_sub(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_sub(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+// v0 + w * d on four floats as two packed FMAs
+__device__ __forceinline__ f32x4 pk_lerp(f32x4 v0, float w, f32x4 d) {
+    const f32x2 w2 = {w, w};
+    const f32x2 lo = __builtin_elementwise_fma(f32x2{d[0], d[1]}, w2, f32x2{v0[0], v0[1]});
+    const f32x2 hi = __builtin_elementwise_fma(f32x2{d[2], d[3]}, w2, f32x2{v0[2], v0[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
 // 8 floats (two accumulator quads: K order x6_chan_of_k) -> three bf16x8 fragments, v = t0 + t1 + t2 exactly
 __device__ __forceinline__ void x6_split8(const float v[8], bf16x8 out[3]) {
     u32x4 t[3];
@@ -44,9 +62,9 @@ __device__ __forceinline__ void x6_split8(const float v[8], bf16x8 out[3]) {
     for (int k = 0; k < 4; ++k) {
         const f32x2 a = {v[2 * k], v[2 * k + 1]};
         const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
-        const f32x2 r = {a[0] - __uint_as_float(h << 16), a[1] - __uint_as_float(h & 0xffff0000u)};
+        const f32x2 r = pk_sub(a, f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)});
         const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
-        const f32x2 q = {r[0] - __uint_as_float(m << 16), r[1] - __uint_as_float(m & 0xffff0000u)};
+        const f32x2 q = pk_sub(r, f32x2{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)});
         t[0][k] = h; t[1][k] = m; t[2][k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(q, bf16x2));
     }
 #pragma unroll
@@ -441,13 +459,13 @@ __global__ __launch_bounds__(V2_THREADS, 2) void head_x6_v2_kernel(HeadParams p,
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(t0 + (r * V2_SIDE0) * PIXB);
                     const f32x4 v1 = *reinterpret_cast<const f32x4*>(t0 + (r * V2_SIDE0 + 1) * PIXB);
                     const f32x4 v2 = *reinterpret_cast<const f32x4*>(t0 + (r * V2_SIDE0 + 2) * PIXB);
-                    h[r][0] = v0 + 0.75f * (v1 - v0);         // (X and Y are even: the 2x branch's weights are constants)
-                    h[r][1] = v1 + 0.25f * (v2 - v1);
+                    h[r][0] = pk_lerp(v0, 0.75f, pk_sub(v1, v0));         // (X and Y are even: the 2x branch's weights are constants)
+                    h[r][1] = pk_lerp(v1, 0.25f, pk_sub(v2, v1));
                 }
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    s[dx] = h[0][dx] + 0.75f * (h[1][dx] - h[0][dx]);
-                    s[2 + dx] = h[1][dx] + 0.25f * (h[2][dx] - h[1][dx]);
+                    s[dx] = pk_lerp(h[0][dx], 0.75f, pk_sub(h[1][dx], h[0][dx]));
+                    s[2 + dx] = pk_lerp(h[1][dx], 0.25f, pk_sub(h[2][dx], h[1][dx]));
                 }
             }
 #pragma unroll
@@ -460,16 +478,16 @@ __global__ __launch_bounds__(V2_THREADS, 2) void head_x6_v2_kernel(HeadParams p,
                 for (int r = 0; r < 2; ++r) {
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(t0 + (r * sd) * PIXB);
                     const f32x4 v1 = *reinterpret_cast<const f32x4*>(t0 + (r * sd + 1) * PIXB);
-                    const f32x4 d = v1 - v0;
-                    h[r][0] = v0 + lx0[b] * d;
-                    h[r][1] = h[r][0] + step * d;
+                    const f32x4 d = pk_sub(v1, v0);
+                    h[r][0] = pk_lerp(v0, lx0[b], d);
+                    h[r][1] = pk_lerp(h[r][0], step, d);
                 }
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    const f32x4 d = h[1][dx] - h[0][dx];
-                    const f32x4 o0 = h[0][dx] + ly0[b] * d;
+                    const f32x4 d = pk_sub(h[1][dx], h[0][dx]);
+                    const f32x4 o0 = pk_lerp(h[0][dx], ly0[b], d);
                     s[dx] += o0;
-                    s[2 + dx] += o0 + step * d;
+                    s[2 + dx] += pk_lerp(o0, step, d);
                 }
             }
 #pragma unroll

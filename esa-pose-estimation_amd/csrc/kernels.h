@@ -228,10 +228,10 @@ int launch_head2(const Head2Params& p, bool ulo, hipStream_t stream);
 bool head_fused2_supported(int H, int W, const int th[3], const int tw[3], int C0p, int C1p, int K, bool* ulo);
 
 // ---- CBAM attention of the seg_hrnet3 variant + slice re-sampling (cbam.hip) --------------------
-int launch_pool_partial(const char* x, float* partial, int N, int HW, int Cp, int P, hipStream_t s);
+int launch_pool_partial(const char* x, float* partial, int N, int HW, int Cp, int P, hipStream_t s, int fmt = FMT_SB);
 int launch_ca_mlp(const float* partial, const float* w0, const float* w2, float* ca, int N, int HW, int C,
                   int Cp, int Cr, int P, hipStream_t s);
-int launch_cbam_maps(const char* x, const float* ca, float* maps, int N, int HW, int C, int Cp, hipStream_t s);
+int launch_cbam_maps(const char* x, const float* ca, float* maps, int N, int HW, int C, int Cp, hipStream_t s, int fmt = FMT_SB);
 struct CbamApplyParams {
     const char* x;      // SB [N][H][W][Cp]
     const char* res;    // SB same shape or nullptr
@@ -241,6 +241,7 @@ struct CbamApplyParams {
     char* y;            // SB, pixel pitch y_pix_bytes, written at channel offset y_c0 (multiple of 8)
     int N, H, W, Cp, y_pix_bytes, y_c0, relu;
     int C;              // real channels (cbam_spatial only: it forms the maps itself and ignores `maps`)
+    int fmt = FMT_SB;   // FMT_SB or FMT_F32 (x, res and y alike)
 };
 int launch_cbam_apply(const CbamApplyParams& p, hipStream_t s);
 // maps + apply in one pass (no `maps` tensor); Cp / 8 must be a power of two <= 32
@@ -265,6 +266,7 @@ struct ResampleParams {
     char* y;            // SB [N][H][W][..], pixel pitch y_pix_bytes, channel offset y_c0 (multiple of 8)
     int N, h, w, H, W, C, Cp_src, y_pix_bytes, y_c0;
     int align;          // 1: align_corners=True, 0: False (irrelevant when h==H && w==W: copy)
+    int fmt = FMT_SB;   // FMT_SB or FMT_F32 (x and y alike)
 };
 int launch_resample_slice(const ResampleParams& p, hipStream_t s);
 int launch_zero_slice(char* y, long long npix, int y_pix_bytes, int c0, int nchan, hipStream_t s);
@@ -276,6 +278,7 @@ struct GatherParams {
     int N, H, W, C, Cp;                 // C real output channels, Cp padded (the padding is written as zeros)
     int h[2], w[2], zpix[2];
     int R[2], Cc[2], ngroups, nreal, gpw;      // filled by the launcher
+    int fmt = FMT_SB;   // y: FMT_SB or FMT_F32 (z is plain f32 in both)
 };
 bool head_gather_supported(int H, int W, const int* h, const int* w, int Cp);
 int launch_head_gather(GatherParams p, hipStream_t stream);

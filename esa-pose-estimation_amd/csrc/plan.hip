@@ -982,7 +982,7 @@ esa::ConvParams conv_params_of(const esahrnet_ctx& c, const Op& o, int n, const 
     p.res = o.res >= 0 ? (ws ? ws + c.tensors[o.res].off : dummy) : nullptr;
     p.w = static_cast<const uint4*>(d.w); p.bias = d.bias;
     p.N = n; p.H = lh[ti.level]; p.W = lw[ti.level]; p.OH = lh[to.level]; p.OW = lw[to.level];
-    p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu; p.out_f32 = d.out_f32; p.fmt = c.fmt;
+    p.Cinp = d.cinp; p.Coutp = d.coutp; p.relu = o.relu; p.out_f32 = d.out_f32 && !c.x6(); p.fmt = c.fmt;      // (fp32-grade: every tensor is plain f32)
     return p;
 }
 
@@ -1165,7 +1165,7 @@ int esahrnet_create(const esahrnet_cfg* cfg, int device, esahrnet_handle* out) {
     if (cfg->variant != 0 && cfg->variant != 1) return fail("variant=%d unsupported (0: seg_hrnet/2, 1: seg_hrnet3)", cfg->variant);
     if (cfg->precision < 0 || cfg->precision > 2)
         return fail("precision=%d unsupported (0: split-bf16 'bf16x3', 1: bf16, 2: fp32-grade 'bf16x6')", cfg->precision);
-    if (cfg->precision != 0 && cfg->variant != 0) return fail("precision %d is built for variant 0 only", cfg->precision);
+    if (cfg->precision == 1 && cfg->variant != 0) return fail("precision 1 (bf16) is built for variant 0 only");
     if (cfg->variant == 1) {
         if (cfg->stem_width % 16) return fail("variant 1: stem_width must be a multiple of 16 (ChannelAttention ratio)");
         for (int b = 0; b < ESAHRNET_MAX_BRANCHES; ++b)
@@ -1513,7 +1513,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
         q.kind = -1;
         const Tensor& tx = h->tensors[o.kind == OP_MLP ? o.terms[0] : o.in];
         const int hh = sp.lh[tx.level], ww = sp.lw[tx.level];
-        q.ap.N = n; q.ap.H = hh; q.ap.W = ww; q.ap.Cp = tx.Cp; q.ap.C = o.nchan;
+        q.ap.N = n; q.ap.H = hh; q.ap.W = ww; q.ap.Cp = tx.Cp; q.ap.C = o.nchan; q.ap.fmt = h->fmt;
         q.HW = hh * ww; q.P = std::min(Builder::POOL_SLABS, q.HW); q.Cr = o.nchan / 16;
         switch (o.kind) {
             case OP_POOL: q.kind = esa::CBAM_POOL; q.ap.x = T(o.in); q.partial = reinterpret_cast<float*>(T(o.out)); q.ap.C = tx.C; break;
@@ -1567,7 +1567,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
             case OP_STEMRAW: {
                 const Tensor& t = h->tensors[o.out];
                 esa::StemParams p{static_cast<const float*>(x_dev), T(o.out), h->stemraw_w, h->stemraw_b,
-                                  n, height, width, h->cfg.cin, t.Cp, 0, 0};
+                                  n, height, width, h->cfg.cin, t.Cp, 0, h->fmt};
                 rc = stem_pools(*h, height, width) ? esa::launch_stem_pool(p, reinterpret_cast<float*>(T(o.out2)), stream)
                                                    : esa::launch_stem(p, stream);
                 break;
@@ -1591,7 +1591,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 if (o.out == h->stemraw_partial && stem_pools(*h, height, width)) break;       // made by the stem kernel
                 const int HW = sp.lh[ti.level] * sp.lw[ti.level];
                 rc = esa::launch_pool_partial(T(o.in), reinterpret_cast<float*>(T(o.out)), n, HW, ti.Cp,
-                                              std::min(Builder::POOL_SLABS, HW), stream);
+                                              std::min(Builder::POOL_SLABS, HW), stream, h->fmt);
                 break;
             }
             case OP_MLP: {
@@ -1608,7 +1608,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 if (cbam_fused(*h, ti.Cp, sp.lh[ti.level], sp.lw[ti.level])) break;      // formed inside cbam_spatial (the OP_APPLY that follows)
                 rc = esa::launch_cbam_maps(T(o.in), reinterpret_cast<const float*>(T(o.terms[1])),
                                            reinterpret_cast<float*>(T(o.out)), n, sp.lh[ti.level] * sp.lw[ti.level],
-                                           o.nchan, ti.Cp, stream);
+                                           o.nchan, ti.Cp, stream, h->fmt);
                 break;
             }
             case OP_APPLY: {
@@ -1619,7 +1619,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 p.ca = reinterpret_cast<const float*>(T(o.terms[1])); p.maps = reinterpret_cast<const float*>(T(o.terms[2]));
                 p.w_sa = h->aux[o.aux[2]].dev; p.y = T(o.out);
                 p.N = n; p.H = sp.lh[ti.level]; p.W = sp.lw[ti.level]; p.Cp = ti.Cp;
-                p.y_pix_bytes = to.Cp * 4; p.y_c0 = o.c0; p.relu = o.relu; p.C = o.nchan;
+                p.y_pix_bytes = to.Cp * 4; p.y_c0 = o.c0; p.relu = o.relu; p.C = o.nchan; p.fmt = h->fmt;
                 rc = cbam_fused(*h, ti.Cp, p.H, p.W) ? esa::launch_cbam_spatial(p, stream) : esa::launch_cbam_apply(p, stream);
                 break;
             }
@@ -1632,7 +1632,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                 esa::ResampleParams p{};
                 p.x = T(o.in); p.y = T(o.out); p.N = n;
                 p.h = sp.lh[ti.level]; p.w = sp.lw[ti.level]; p.H = sp.lh[to.level]; p.W = sp.lw[to.level];
-                p.C = o.nchan; p.Cp_src = ti.Cp; p.y_pix_bytes = to.Cp * 4; p.y_c0 = o.c0; p.align = o.align;
+                p.C = o.nchan; p.Cp_src = ti.Cp; p.y_pix_bytes = to.Cp * 4; p.y_c0 = o.c0; p.align = o.align; p.fmt = h->fmt;
                 rc = esa::launch_resample_slice(p, stream);
                 break;
             }
@@ -1644,7 +1644,7 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                     const Tensor& tz = h->tensors[zt[b]];
                     p.z[b] = T(zt[b]); p.h[b] = sp.lh[tz.level]; p.w[b] = sp.lw[tz.level]; p.zpix[b] = tz.Cp * 4;
                 }
-                p.y = T(o.out); p.N = n; p.H = sp.lh[to.level]; p.W = sp.lw[to.level]; p.C = to.C; p.Cp = to.Cp;
+                p.y = T(o.out); p.N = n; p.H = sp.lh[to.level]; p.W = sp.lw[to.level]; p.C = to.C; p.Cp = to.Cp; p.fmt = h->fmt;
                 rc = esa::launch_head_gather(p, stream);
                 break;
             }
@@ -1656,8 +1656,8 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
             }
             case OP_TONCHW: {
                 const Tensor& ti = h->tensors[o.in];
-                rc = esa::launch_sb_to_nchw(T(o.in), n, h->cfg.num_keypoints, height, width, ti.Cp,
-                                            static_cast<float*>(heat_dev), stream);
+                rc = esa::launch_fmt_to_nchw(h->fmt, T(o.in), n, h->cfg.num_keypoints, height, width, ti.Cp,
+                                             static_cast<float*>(heat_dev), stream);
                 break;
             }
             case OP_STEMF: {
@@ -1955,7 +1955,7 @@ int esahrnet_op_desc_get(esahrnet_handle h, int index, int n, int height, int wi
                 const Tensor& ti = h->tensors[o.in];
                 esa::ConvParams q{};
                 q.N = n; q.H = lh[ti.level]; q.W = lw[ti.level]; q.OH = lh[to.level]; q.OW = lw[to.level];
-                q.Cinp = d.cinp; q.Coutp = d.coutp; q.out_f32 = d.out_f32; q.fmt = h->fmt;
+                q.Cinp = d.cinp; q.Coutp = d.coutp; q.out_f32 = d.out_f32 && !h->x6(); q.fmt = h->fmt;
                 q.res = o.res >= 0 ? reinterpret_cast<const char*>(h) : nullptr;     // only tested against nullptr
                 snprintf(out->kernel, sizeof out->kernel, "%s", esa::conv_kernel_name(q, s.k, s.stride));
             }

@@ -121,6 +121,31 @@ __device__ __forceinline__ void join8(uint4 hi, uint4 lo, float v[8]) {
     join4(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), v + 4);
 }
 
+// 8 channels of a pixel are 32 bytes in SB ([hi 16 B | lo 16 B]) and in the fp32-grade mode's plain f32 NHWC alike; the
+// memory-bound kernels (cbam.hip, head_gather.hip, the raw stem) serve both through these (f32: a uniform run-time flag)
+__device__ __forceinline__ void join8_fmt(uint4 a, uint4 b, float v[8], bool f32) {
+    if (f32) {
+        v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.y); v[2] = __uint_as_float(a.z); v[3] = __uint_as_float(a.w);
+        v[4] = __uint_as_float(b.x); v[5] = __uint_as_float(b.y); v[6] = __uint_as_float(b.z); v[7] = __uint_as_float(b.w);
+    } else {
+        join8(a, b, v);
+    }
+}
+__device__ __forceinline__ void load8_fmt(const char* p, float v[8], bool f32) {
+    join8_fmt(*reinterpret_cast<const uint4*>(p), *reinterpret_cast<const uint4*>(p + 16), v, f32);
+}
+__device__ __forceinline__ void store8_fmt(char* p, const float v[8], bool f32) {
+    uint4 a, b;
+    if (f32) {
+        a = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+        b = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+    } else {
+        split8(v, a, b);
+    }
+    *reinterpret_cast<uint4*>(p) = a;
+    *reinterpret_cast<uint4*>(p + 16) = b;
+}
+
 // ---- "BF" = single bf16 NHWC (esahrnet_cfg.precision == 1, BASELINE configs[3]) ---------------------------------
 // A tensor [N][H][W][Cp] of plain bf16, Cp = channels padded to a multiple of 64 with exact zeros: 2 bytes per
 // channel, half of SB.  A pixel's channels come in 64-channel blocks of 128 bytes = 8 chunks of 16 bytes (8

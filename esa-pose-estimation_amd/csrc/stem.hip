@@ -188,7 +188,7 @@ int stem_pool_slabs(int cin, int cout, int H, int W) {
 // conv1 as launch_stem computes it + per-slab (sum, max) of every channel into pool[N][slabs][cout][2]
 int launch_stem_pool(const StemParams& p, float* pool, hipStream_t stream) {
     const int slabs = stem_pool_slabs(p.cin, p.cout, p.H, p.W);
-    if (!slabs || !pool || p.fmt != FMT_SB || (long long)p.N * p.H > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    if (!slabs || !pool || (p.fmt != FMT_SB && p.fmt != FMT_F32) || (long long)p.N * p.H > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const int xgroups = (p.W + STEM_PX - 1) / STEM_PX;
     const dim3 grid((unsigned)((xgroups * (p.cout >> 3) + 255) / 256), (unsigned)(p.N * p.H));
     hipLaunchKernelGGL(stem1_kernel<true>, grid, dim3(256), 0, stream, p, xgroups, 0LL, pool);

@@ -7,7 +7,6 @@ from .hrnet import HighResolutionNet as _Base
 
 class HighResolutionNet(_Base):
     CIN, NUM_KEYPOINTS, VARIANT = 1, 30, 1
-    DEFAULT_PRECISION = "bf16x3"     # the CBAM kernels (cbam.hip, head_gather.hip) exist for the split-bf16 format only
 
 
 def get_seg_model(cfg, **kwargs):
