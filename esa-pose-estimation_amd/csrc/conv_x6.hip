@@ -235,8 +235,14 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     };
 
     float* const w1s = reinterpret_cast<float*>(smem + C::LDS);     // STEM: conv1's folded weights + bias, [chunk][sg][10][8]
+    // STEM: the raw crop under a tile of conv1's output (tile + one pixel each side, zeros beyond the image: conv1's padding),
+    // two buffers: the crop of step s+2 is loaded at the start of step s (one or two loads per thread), written here at its
+    // end and consumed by the staging of step s+1 — every conv1 input then comes from LDS with a compile-time offset (read
+    // per unit from global memory, the nine bounds-checked addresses per unit cost more VALU than conv1 itself).
+    constexpr int RW = C::IW + 2, RH = C::IH + 2, RAWN = RW * RH, RIT = STEM ? (RAWN + C::NT - 1) / C::NT : 1;
+    float* const rawt = w1s + 2 * 4 * 10 * 8;
     if (STEM) {
-        for (int i = tid; i < 2 * 4 * 10 * 8; i += C::NT) w1s[i] = stem.w1[i];      // (published by the loop's first barrier)
+        for (int i = tid; i < 2 * 4 * 10 * 8; i += C::NT) w1s[i] = stem.w1[i];      // (published by the prologue's barrier)
     }
     // ---- staging map: thread -> (k-group sg, tile pixel q0 + QSTEP*it), fixed for the launch ----
     const int sg = tid & 3, q0 = tid >> 2;
@@ -246,6 +252,11 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         const int q = q0 + it * QSTEP;
         const int qy = q / C::IW, qx = q - qy * C::IW;
         qyx[it] = q < C::NPIX ? (qy << 8 | qx) : -1;
+    }
+    int roff[STEM ? XITER : 1];                 // STEM: the unit's pixel in the raw crop tile (its 3x3 window's first element)
+    if constexpr (STEM) {
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) roff[it] = qyx[it] >= 0 ? (qyx[it] >> 8) * RW + (qyx[it] & 255) : 0;
     }
     // The tile of step s+1 is staged INSIDE step s in two halves (units [0, XH) and [XH, XITER)): loads at the start of a
     // phase, split + LDS writes behind it — a unit lives in registers for one phase, not for a whole step.
@@ -258,9 +269,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     constexpr int XH = (KS == 1 || DEEP || NBUF == 1) ? XITER : (XITER + 1) / 2;
     u32x4 xr[STEM ? 1 : XH][2];                 // the half in flight: two quads of 4 channels per unit
     u32x4 xn[DEEP ? XITER : 1][2];              // DEEP: the tile two steps ahead
-    float rawv[STEM ? XH : 1][9];               // STEM: the unit's 3x3 neighbourhood of the raw crop
-    uint32_t rmask[STEM ? XH : 1];              //       and ~0 / 0: is its pixel inside conv1's output (else conv2's zero padding)?
-    int rchunk = 0;                             //       channel chunk of the half in flight
+    float rawreg[RIT];                          // STEM: this thread's pixels of the raw crop two steps ahead
     // byte offsets of the staged item's units inside its image (X6_OOB beyond the image: the zero padding); they change with
     // the item, not with the chunk: recomputed by tile_offsets() when the stream moves to a new item
     uint32_t xoff[STEM ? 1 : XITER];
@@ -277,24 +286,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     };
     auto load_tile = [&](const X6Pos& q, auto half_c) __attribute__((always_inline)) {
         constexpr int i0 = decltype(half_c)::value * XH;
-        if constexpr (STEM) {
-            const uint32_t rimg = (uint32_t)p.H * p.W * 4;
-            const __amdgpu_buffer_rsrc_t rx = x6_rsrc(stem.x0 + (size_t)q.n * p.H * p.W, q.ok ? rimg : 0u);
-            const int gy0 = q.oy0 * S - C::PAD, gx0 = q.ox0 * S - C::PAD;
-            rchunk = q.c;
-#pragma unroll
-            for (int it = i0; it < i0 + XH && it < XITER; ++it) {
-                const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
-                rmask[it - i0] = (qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? 0xffffffffu : 0u;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
-                    const bool in = qyx[it] >= 0 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                    rawv[it - i0][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, in ? (yy * p.W + xx) * 4 : (int)X6_OOB, 0, 0));
-                }
-            }
-            return;
-        }
+        if constexpr (STEM) return;       // (raw_load / stage_stem below)
         const __amdgpu_buffer_rsrc_t rx = x6_rsrc(p.x + (size_t)q.n * ximg, q.ok ? ximg : 0u);      // (no step behind: zeros, no traffic)
         const int so = q.c * 128;
 #pragma unroll
@@ -321,26 +313,92 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     };
     char* const xwr = smem + q0 * 16 + sg * (3 * C::PLANE) + (S == 2 ? (sg & 1) * 16 : 0);      // plane_off(sg, 0) + pixel slot
     // unit `it` of the half in flight: split into three exact bf16 terms, three 16-byte LDS writes
+    // split into three exact bf16 terms + three 16-byte LDS writes of one unit's 8 channels
+    auto emit_unit = [&](int buf, int it, const u32x4 (&src)[2]) __attribute__((always_inline)) {
+        u32x4 t0, t1, t2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                uint32_t a, b, c;
+                x6_split_pair(__uint_as_float(src[h][2 * k]), __uint_as_float(src[h][2 * k + 1]), a, b, c);
+                t0[2 * h + k] = a; t1[2 * h + k] = b; t2[2 * h + k] = c;
+            }
+        char* o = xwr + buf * C::XBYTES + it * (QSTEP * 16);
+        if ((it + 1) * QSTEP <= C::NPIX || q0 + it * QSTEP < C::NPIX) {       // (only the tile's last unit is partial)
+            *reinterpret_cast<u32x4*>(o) = t0;
+            *reinterpret_cast<u32x4*>(o + C::PLANE) = t1;
+            *reinterpret_cast<u32x4*>(o + 2 * C::PLANE) = t2;
+        }
+    };
+    // STEM: the raw crop of position q -> registers (zeros beyond the image), registers -> LDS
+    auto raw_load = [&](const X6Pos& q) __attribute__((always_inline)) {
+        if constexpr (STEM) {
+            const uint32_t rimg = (uint32_t)p.H * p.W * 4;
+            const __amdgpu_buffer_rsrc_t rx = x6_rsrc(stem.x0 + (size_t)q.n * p.H * p.W, q.ok ? rimg : 0u);
+            const int gy0 = q.oy0 * S - C::PAD - 1, gx0 = q.ox0 * S - C::PAD - 1;
+#pragma unroll
+            for (int k = 0; k < RIT; ++k) {
+                const int i = tid + k * C::NT;
+                const int ry = i / RW, rx_ = i - ry * RW;
+                const int yy = gy0 + ry, xx = gx0 + rx_;
+                const bool in = i < RAWN && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                rawreg[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, in ? (yy * p.W + xx) * 4 : (int)X6_OOB, 0, 0));
+            }
+        }
+    };
+    auto raw_commit = [&](int rb) __attribute__((always_inline)) {
+        if constexpr (STEM) {
+#pragma unroll
+            for (int k = 0; k < RIT; ++k)
+                if (RAWN % C::NT == 0 || k + 1 < RIT || tid + k * C::NT < RAWN) rawt[rb * RAWN + tid + k * C::NT] = rawreg[k];
+        }
+    };
+    // STEM: conv1 + bn1 + ReLU of ALL units of position q's tile (channels q.c*32 + x6_chan_of_k(sg, 0..7)) from raw crop
+    // buffer rb -> tile buffer buf.  Taps outermost: a tap's 8 weights (LDS) serve every unit.
+    auto stage_stem = [&](int buf, const X6Pos& q, int rb) __attribute__((always_inline)) {
+        if constexpr (STEM) {
+            const float* wt = w1s + (q.c * 4 + sg) * 80;
+            const float* rt = rawt + rb * RAWN;
+            const int gy0 = q.oy0 * S - C::PAD, gx0 = q.ox0 * S - C::PAD;
+            f32x4 a0[XITER], a1[XITER];
+            {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(wt + 72), b1 = *reinterpret_cast<const f32x4*>(wt + 76);
+#pragma unroll
+                for (int it = 0; it < XITER; ++it) { a0[it] = b0; a1[it] = b1; }
+            }
+            x6_static_for<0, 9>([&](auto t_c) __attribute__((always_inline)) {
+                constexpr int t = decltype(t_c)::value;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + t * 8), w1v = *reinterpret_cast<const f32x4*>(wt + t * 8 + 4);
+                x6_static_for<0, XITER>([&](auto it_c) __attribute__((always_inline)) {
+                    constexpr int it = decltype(it_c)::value;
+                    const float v = rt[roff[it] + (t / 3) * RW + t % 3];
+                    a0[it] = __builtin_elementwise_fma(f32x4{v, v, v, v}, w0, a0[it]);
+                    a1[it] = __builtin_elementwise_fma(f32x4{v, v, v, v}, w1v, a1[it]);
+                });
+            });
+            x6_static_for<0, XITER>([&](auto it_c) __attribute__((always_inline)) {
+                constexpr int it = decltype(it_c)::value;
+                // outside conv1's output: conv2's zero padding, not conv1 of the padded crop
+                const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
+                const uint32_t m = (qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? 0xffffffffu : 0u;
+                u32x4 src[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    src[0][k] = __float_as_uint(relu1(a0[it][k])) & m;
+                    src[1][k] = __float_as_uint(relu1(a1[it][k])) & m;
+                }
+                emit_unit(buf, it, src);
+            });
+        }
+    };
     auto write_unit = [&](int buf, int i0, int it) __attribute__((always_inline)) {
         {
             if (it >= XITER || (X6_ABL & 2)) return;
             u32x4 t0, t1, t2;
             u32x4 src[2];
-            if constexpr (STEM) {       // conv1 + bn1 + ReLU of the unit's pixel, channels rchunk*32 + x6_chan_of_k(sg, 0..7)
-                const float* wt = w1s + (rchunk * 4 + sg) * 80;
-                f32x4 a0 = *reinterpret_cast<const f32x4*>(wt + 72), a1 = *reinterpret_cast<const f32x4*>(wt + 76);      // bias
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + t * 8), w1v = *reinterpret_cast<const f32x4*>(wt + t * 8 + 4);
-                    const float v = rawv[it - i0][t];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { a0[k] = fmaf(v, w0[k], a0[k]); a1[k] = fmaf(v, w1v[k], a1[k]); }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    src[0][k] = __float_as_uint(relu1(a0[k])) & rmask[it - i0];
-                    src[1][k] = __float_as_uint(relu1(a1[k])) & rmask[it - i0];
-                }
+            if constexpr (STEM) {
+                src[0] = u32x4{0u, 0u, 0u, 0u}; src[1] = src[0];      // (never called: stage_stem)
             } else {
                 src[0] = xr[it - i0][0];
                 src[1] = xr[it - i0][1];
@@ -387,14 +445,26 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         for (int it = i0; it < i0 + XH; ++it) write_unit(buf, i0, it);
     };
     tile_offsets(cur);
-    load_tile(cur, H0);
-    write_tile(0, H0);
-    if constexpr (XH < XITER) {
-        load_tile(cur, H1);
-        write_tile(0, H1);
+    if constexpr (STEM) {
+        raw_load(cur);
+        raw_commit(0);
+        __syncthreads();            // (also publishes w1s)
+        stage_stem(0, cur, 0);
+    } else {
+        load_tile(cur, H0);
+        write_tile(0, H0);
+        if constexpr (XH < XITER) {
+            load_tile(cur, H1);
+            write_tile(0, H1);
+        }
     }
     X6Pos nxt = advance(cur);
     if (nxt.c == 0) tile_offsets(nxt);
+    if constexpr (STEM) {
+        raw_load(nxt);
+        raw_commit(1);              // (published by the loop's first barrier)
+    }
+    int sidx = 0;
     if constexpr (DEEP) load_next(nxt);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -410,8 +480,9 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     int pstep = 0;
 #ifdef X6_TRACE
     int tstep = 0;
-    const bool ton = KS == 3 && S == X6_TRACE && bid < 64 && tid == 0;
-    const bool wgon = KS == 3 && S == X6_TRACE && bid < 1024 && tid == 0;
+    constexpr bool TSEL = KS == 3 && (X6_TRACE == 3 ? STEM : (S == X6_TRACE && !STEM));      // (-DX6_TRACE=3: the fused stem)
+    const bool ton = TSEL && bid < 64 && tid == 0;
+    const bool wgon = TSEL && bid < 1024 && tid == 0;
     if (wgon) {
         g_x6_wg[bid * 4] = __builtin_amdgcn_s_memrealtime();
         g_x6_wg[bid * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -436,6 +507,11 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         if (!(X6_ABL & 32)) __syncthreads();        // tile of this step published; every wave is done reading the other buffer
         X6_TR(1)
         const bool last_chunk = cur.c + 1 == nchunks;
+        X6Pos nn = nxt;
+        if constexpr (STEM) {       // the raw crop two steps ahead
+            nn = advance(nxt);
+            raw_load(nn);
+        }
         // Every load of the loop is UNCONDITIONAL (the next step's weight thirds even when they are the ones already held or
         // no step follows, the residual rows and the output stores of a step that does not end its item with out-of-range
         // offsets: an issue slot, no traffic): with a load behind a run-time branch hipcc cannot count what is in flight at
@@ -545,7 +621,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                 }
                 if constexpr (EPI && r + RCN - 1 < NR) res_load(r + RCN - 1);      // into the slot the epilogue above has just read
                 // staging units of this row: the last XH rows take one each (short phases several)
-                if constexpr (r < NR) {
+                if constexpr (!STEM && r < NR) {
                     constexpr int ucount = x6_units_in_row(NR, XH, NUNITS, r), ufirst = x6_first_unit_in_row(NR, XH, NUNITS, r);
                     x6_static_for<0, ucount>([&](auto u_c) __attribute__((always_inline)) {
                         write_unit(buf ^ 1, WH * XH, WH * XH + ufirst + decltype(u_c)::value);
@@ -578,7 +654,8 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             X6_TR(5)
             load_w(wct, wch, 2);
             __syncthreads();            // every wave is done reading the tile
-            write_tile(0, H0);          // (published by the barrier at the top of the next step)
+            if constexpr (STEM) stage_stem(0, nxt, (sidx + 1) & 1);
+            else write_tile(0, H0);     // (published by the barrier at the top of the next step)
         } else if constexpr (KS == 3) {
             // The tile of step s+1 goes to the other buffer (free since the barrier) half by half: loads at the start of phases
             // 0 / 1, split + LDS writes in those phases' last rows.  The weight third a phase has used is refilled for step
@@ -597,6 +674,10 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             asm volatile("" : "+v"(bvn));       // the bias load is complete here (older than the tile half just consumed): waited
                                                 // for now, with a counted vmcnt, not at the next step's start behind the weight loads
             X6_TR(3)
+            if constexpr (STEM) {       // conv1 of the next tile, between two phases (inside one the operand ring leaves no registers)
+                stage_stem(buf ^ 1, nxt, (sidx + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (XH < XITER) load_tile(nxt, H1);
             load_w(wct, wch, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -628,10 +709,16 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
 #ifdef X6_TRACE
         if (wgon && !nxt.ok) { g_x6_wg[bid * 4 + 1] = __builtin_amdgcn_s_memrealtime(); g_x6_wg[bid * 4 + 2] = tstep; }
 #endif
+        if constexpr (STEM) raw_commit(sidx & 1);       // crop of step s+2 (this buffer's readers were step s-1's staging)
+        ++sidx;
         if (!nxt.ok) break;
         cur = nxt;
-        nxt = advance(cur);
-        if (nxt.c == 0) tile_offsets(nxt);      // (a uniform branch around integer VALU only)
+        if constexpr (STEM) {
+            nxt = nn;
+        } else {
+            nxt = advance(cur);
+            if (nxt.c == 0) tile_offsets(nxt);      // (a uniform branch around integer VALU only)
+        }
         if constexpr (NBUF == 2) buf ^= 1;
     }
 }
@@ -1010,7 +1097,7 @@ int launch_stem_fused_x6(const StemFusedParams& sp, hipStream_t stream) {
     const int slots = 2 * device_cus();
     int grid = (int)(nitems < slots ? nitems : slots);
     if (grid > geo.ctiles) grid -= grid % geo.ctiles;
-    constexpr int LDS = C::LDS + 2 * 4 * 10 * 8 * 4;
+    constexpr int LDS = C::LDS + 2 * 4 * 10 * 8 * 4 + 2 * (C::IW + 2) * (C::IH + 2) * 4;       // tiles, conv1 weights, raw crops
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(stem_x6_kernel), LDS)) return e_;
     X6StemSrc src{sp.x, sp.w1};
     hipLaunchKernelGGL(stem_x6_kernel, dim3((unsigned)grid), dim3(NTHREADS), LDS, stream, p, geo, src);

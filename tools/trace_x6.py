@@ -11,6 +11,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from esa_pose_estimation_amd import _lib, synth  # noqa: E402
 
+STEM = len(sys.argv) > 1 and sys.argv[1] == "stem"        # build with -DX6_TRACE=3: one seg_hrnet2 forward, the fused stem's stamps
+if STEM:
+    sys.argv = sys.argv[:1]
 n, cin, cout, h, w = [int(v) for v in (sys.argv[1:6] if len(sys.argv) > 5 else (128, 64, 64, 64, 64))]
 stride = int(sys.argv[6]) if len(sys.argv) > 6 else 1        # build with -DX6_TRACE=<stride>
 lib = _lib.lib()
@@ -20,7 +23,16 @@ x = torch.from_numpy(synth.normal("x", 1, (n, cin, h, w))).cuda()
 wt = synth.normal("w", 2, (cout, cin, 3, 3), float(np.sqrt(1.0 / (cin * 9))))
 b = synth.normal("b", 3, (cout,), 0.1)
 y = torch.empty((n, cout, (h + stride - 1) // stride, (w + stride - 1) // stride), device="cuda")
-for _ in range(2):
+if STEM:
+    from esa_pose_estimation_amd import config, seg_hrnet2
+    net = seg_hrnet2.get_seg_model(config.make_config())
+    net.load_state_dict(synth.make_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=0))
+    net = net.cuda().eval()
+    xs = synth.make_crops(32, 1, 256, 256, seed=1).cuda()
+    with torch.no_grad():
+        for _ in range(3):
+            net(xs)
+for _ in range(0 if STEM else 2):
     _lib.check(lib.esahrnet_op_conv_ex(x.data_ptr(), n, cin, h, w, wt.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
                                        cout, 3, stride, 1, None, y.data_ptr(), 2, st))
 torch.cuda.synchronize()
