@@ -361,34 +361,39 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             const float* wt = w1s + (q.c * 4 + sg) * 80;
             const float* rt = rawt + rb * RAWN;
             const int gy0 = q.oy0 * S - C::PAD, gx0 = q.ox0 * S - C::PAD;
-            f32x4 a0[XITER], a1[XITER];
-            {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(wt + 72), b1 = *reinterpret_cast<const f32x4*>(wt + 76);
+            constexpr int UG = XITER <= 3 ? 3 : 2;       // units per pass (their 8-channel accumulators: 8 registers each)
+            x6_static_for<0, (XITER + UG - 1) / UG>([&](auto g_c) __attribute__((always_inline)) {
+                constexpr int u0 = decltype(g_c)::value * UG, un = XITER - u0 < UG ? XITER - u0 : UG;
+                f32x4 a0[un], a1[un];
+                {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(wt + 72), b1 = *reinterpret_cast<const f32x4*>(wt + 76);
 #pragma unroll
-                for (int it = 0; it < XITER; ++it) { a0[it] = b0; a1[it] = b1; }
-            }
-            x6_static_for<0, 9>([&](auto t_c) __attribute__((always_inline)) {
-                constexpr int t = decltype(t_c)::value;
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + t * 8), w1v = *reinterpret_cast<const f32x4*>(wt + t * 8 + 4);
-                x6_static_for<0, XITER>([&](auto it_c) __attribute__((always_inline)) {
-                    constexpr int it = decltype(it_c)::value;
-                    const float v = rt[roff[it] + (t / 3) * RW + t % 3];
-                    a0[it] = __builtin_elementwise_fma(f32x4{v, v, v, v}, w0, a0[it]);
-                    a1[it] = __builtin_elementwise_fma(f32x4{v, v, v, v}, w1v, a1[it]);
-                });
-            });
-            x6_static_for<0, XITER>([&](auto it_c) __attribute__((always_inline)) {
-                constexpr int it = decltype(it_c)::value;
-                // outside conv1's output: conv2's zero padding, not conv1 of the padded crop
-                const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
-                const uint32_t m = (qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? 0xffffffffu : 0u;
-                u32x4 src[2];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    src[0][k] = __float_as_uint(relu1(a0[it][k])) & m;
-                    src[1][k] = __float_as_uint(relu1(a1[it][k])) & m;
+                    for (int u = 0; u < un; ++u) { a0[u] = b0; a1[u] = b1; }
                 }
-                emit_unit(buf, it, src);
+                x6_static_for<0, 9>([&](auto t_c) __attribute__((always_inline)) {
+                    constexpr int t = decltype(t_c)::value;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + t * 8), w1v = *reinterpret_cast<const f32x4*>(wt + t * 8 + 4);
+                    x6_static_for<0, un>([&](auto u_c) __attribute__((always_inline)) {
+                        constexpr int u = decltype(u_c)::value;
+                        const float v = rt[roff[u0 + u] + (t / 3) * RW + t % 3];
+                        a0[u] = __builtin_elementwise_fma(f32x4{v, v, v, v}, w0, a0[u]);
+                        a1[u] = __builtin_elementwise_fma(f32x4{v, v, v, v}, w1v, a1[u]);
+                    });
+                });
+                x6_static_for<0, un>([&](auto u_c) __attribute__((always_inline)) {
+                    constexpr int u = decltype(u_c)::value, it = u0 + u;
+                    // outside conv1's output: conv2's zero padding, not conv1 of the padded crop
+                    const int gy = gy0 + (qyx[it] >> 8), gx = gx0 + (qyx[it] & 255);
+                    const uint32_t m = (qyx[it] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? 0xffffffffu : 0u;
+                    u32x4 src[2];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        src[0][k] = __float_as_uint(relu1(a0[u][k])) & m;
+                        src[1][k] = __float_as_uint(relu1(a1[u][k])) & m;
+                    }
+                    emit_unit(buf, it, src);
+                });
+                __builtin_amdgcn_sched_barrier(0);
             });
         }
     };
