@@ -55,7 +55,7 @@ typedef struct esahrnet_cfg {
                                     2: "bf16x6" — fp32-grade, THE MODE OF configs[1] / configs[2] (the reference computes in
                                        fp32, models/seg_hrnet.py:425-473): f32 NHWC activations, every operand split exactly
                                        into three bf16 terms, 6 MFMAs per product, f32 accumulate; error vs fp64 at or below
-                                       that of an f32 FMA chain; variant 0 only;
+                                       that of an f32 FMA chain; both variants;
                                     0: "bf16x3" — split-bf16 hi/lo operands (~16 significand bits), 3 MFMAs per product, f32
                                        accumulate: heatmap L_inf ~1e-5 of the heat-map scale; opt-in fast mode, NOT fp32;
                                     1: bf16 activations and weights stored ONCE (half the bytes, one MFMA per
