@@ -486,3 +486,28 @@ def test_hrnet3_cbam_forms_agree(env, monkeypatch):
         y2 = net2(x).clone()
     assert torch.equal(y, y1)
     assert (y - y2).abs().max().item() <= 2e-6 * max(1.0, y.abs().max().item())
+
+
+def test_hrnet3_batch_properties_and_graph_replay(env):
+    """seg_hrnet3 at the bench shape's topology (W32, 30 keypoints): every sample equals its own batch-1 forward bit for bit
+    (no kernel choice depends on the batch), permutation equivariance, HIP-graph replay identical to the eager forward."""
+    net, sd = _build(env, "seg_hrnet3", (32, 64, 128, 256), 17)
+    x = env["synth"].make_crops(6, 1, 128, 128, seed=17).cuda()
+    xc = x.clone()
+    with torch.no_grad():
+        y = net(x).clone()
+        ys = [net(x[i:i + 1]).clone() for i in (0, 5)]
+        perm = torch.tensor([3, 0, 5, 1, 4, 2], device="cuda")
+        yp = net(x[perm]).clone()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            yg = net(x)
+        gph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x, xc) and torch.isfinite(y).all()
+    for i, y1 in zip((0, 5), ys):
+        assert torch.equal(y[i:i + 1], y1), i
+    assert torch.equal(yp, y[perm])
+    assert torch.equal(yg, y)
+    kp = env["inference"].heatmaps_to_keypoints(y)
+    assert kp.shape == (6, 30, 3) and bool(torch.isfinite(kp).all())
