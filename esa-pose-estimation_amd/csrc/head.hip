@@ -15,8 +15,8 @@
 namespace esa {
 namespace {
 
-constexpr int FTH = 8, FTW = 32;            // output tile
-constexpr int FIH = FTH + 2, FIW = FTW + 2; // halo'd input tile
+constexpr int FTW = 32;                     // output tile: 32 columns x 8 * RPT rows (a thread owns RPT vertically adjacent pixels)
+constexpr int FIW = FTW + 2;                // halo'd input tile width
 constexpr int FROW = FIW + 1;               // LDS row pitch (floats)
 
 struct LerpT {
@@ -35,8 +35,21 @@ __device__ __forceinline__ LerpT lerp_ac_true(int dst, int in, int out) {
     return r;
 }
 
-template <int KT>
+__device__ __forceinline__ LerpT lerp_ac_scaled(int dst, int in, float scale) {      // lerp_ac_true with its scale given
+    const float src = scale * (float)dst;
+    LerpT r;
+    r.i0 = min((int)src, in - 1);
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+// RPT = 2: the two pixels of a thread share 12 of their 18 tile reads per channel and every weight, and their
+// multiply-adds pair up as v_pk_fma_f32 (same order per pixel as RPT = 1: bit-identical) — 102 -> ~60 us at W32 256^2.
+template <int KT, int RPT>
 __global__ __launch_bounds__(256) void final_kernel(FinalParams p, int tiles_x, int tiles_y) {
+    constexpr int FTH = 8 * RPT, FIH = FTH + 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);       // [K+cin][FIH][FROW]
     const int CT = p.K + p.cin;
@@ -47,7 +60,9 @@ __global__ __launch_bounds__(256) void final_kernel(FinalParams p, int tiles_x, 
     const int oy0 = ty * FTH, ox0 = tx * FTW;
 
     // ---- stage: up-sampled keypoint channels, 8 at a time per thread ------------------------
-    const int G = (p.K + 7) >> 3;
+    constexpr int G = (KT + 7) >> 3;        // (K <= KT: groups past K hold nothing the compute loop reads)
+    // ATen align_corners=True: scale = (in-1)/(out-1), src = scale*dst — the two divisions once per thread, not per unit
+    const float sc_y = p.H > 1 ? (float)(p.h - 1) / (float)(p.H - 1) : 0.f, sc_x = p.W > 1 ? (float)(p.wd - 1) / (float)(p.W - 1) : 0.f;
     for (int u = threadIdx.x; u < FIH * FIW * G; u += 256) {
         const int c8 = u % G;
         const int q = u / G;
@@ -57,7 +72,7 @@ __global__ __launch_bounds__(256) void final_kernel(FinalParams p, int tiles_x, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = 0.f;
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-            const LerpT ly = lerp_ac_true(gy, p.h, p.H), lx = lerp_ac_true(gx, p.wd, p.W);
+            const LerpT ly = lerp_ac_scaled(gy, p.h, sc_y), lx = lerp_ac_scaled(gx, p.wd, sc_x);
             const size_t r0 = ((size_t)n * p.h + ly.i0) * p.wd, r1 = ((size_t)n * p.h + ly.i1) * p.wd;
             const size_t ps = (size_t)p.Cp * (p.fmt == FMT_BF ? 2 : 4);
             float v00[8], v01[8], v10[8], v11[8];
@@ -100,40 +115,80 @@ __global__ __launch_bounds__(256) void final_kernel(FinalParams p, int tiles_x, 
     }
     __syncthreads();
 
-    // ---- compute: one pixel per thread, all K outputs ------------------------------------------
-    const int lx = threadIdx.x & (FTW - 1), lyy = threadIdx.x / FTW;
-    float acc[KT];
+    // ---- compute: RPT pixels per thread, all K outputs ----------------------------------------
+    const int lx = threadIdx.x & (FTW - 1), lyy = (threadIdx.x / FTW) * RPT;
+    if constexpr (RPT == 2) {
+        f32x2 acc[KT];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) acc[k] = p.bias[k];
-    for (int c = 0; c < CT; ++c) {
-        const float* tp = tile + (c * FIH + lyy) * FROW + lx;
-        const float* wp = p.w + (size_t)c * 9 * KT;
+        for (int k = 0; k < KT; ++k) acc[k] = f32x2{p.bias[k], p.bias[k]};
+        for (int c = 0; c < CT; ++c) {
+            const float* tp = tile + (c * FIH + lyy) * FROW + lx;
+            const float* wp = p.w + (size_t)c * 9 * KT;
+            float r[4][3];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const float v = tp[(tap / 3) * FROW + (tap % 3)];
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int k = 0; k < KT; ++k) acc[k] = fmaf(v, wp[tap * KT + k], acc[k]);
+                for (int j = 0; j < 3; ++j) r[i][j] = tp[i * FROW + j];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const f32x2 v = {r[tap / 3][tap % 3], r[tap / 3 + 1][tap % 3]};
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const float w = wp[tap * KT + k];
+                    acc[k] = __builtin_elementwise_fma(v, f32x2{w, w}, acc[k]);
+                }
+            }
+        }
+        const int ox = ox0 + lx;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int oy = oy0 + lyy + rr;
+            if (oy < p.H && ox < p.W) {
+#pragma unroll
+                for (int k = 0; k < KT; ++k)
+                    if (k < p.K) p.out[(((size_t)n * p.K + k) * p.H + oy) * p.W + ox] = acc[k][rr];
+            }
+        }
+    } else {
+        float acc[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[k] = p.bias[k];
+        for (int c = 0; c < CT; ++c) {
+            const float* tp = tile + (c * FIH + lyy) * FROW + lx;
+            const float* wp = p.w + (size_t)c * 9 * KT;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float v = tp[(tap / 3) * FROW + (tap % 3)];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) acc[k] = fmaf(v, wp[tap * KT + k], acc[k]);
+            }
+        }
+        const int oy = oy0 + lyy, ox = ox0 + lx;
+        if (oy < p.H && ox < p.W) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+                if (k < p.K) p.out[(((size_t)n * p.K + k) * p.H + oy) * p.W + ox] = acc[k];
         }
     }
-    const int oy = oy0 + lyy, ox = ox0 + lx;
-    if (oy < p.H && ox < p.W) {
-#pragma unroll
-        for (int k = 0; k < KT; ++k)
-            if (k < p.K) p.out[(((size_t)n * p.K + k) * p.H + oy) * p.W + ox] = acc[k];
-    }
 }
-
-template <int KT>
-int launch_final_t(const FinalParams& p, hipStream_t stream) {
+template <int KT, int RPT>
+int launch_final_rt(const FinalParams& p, hipStream_t stream) {
+    constexpr int FTH = 8 * RPT, FIH = FTH + 2;
     const int tiles_x = (p.W + FTW - 1) / FTW, tiles_y = (p.H + FTH - 1) / FTH;
     const long long nblk = (long long)p.N * tiles_x * tiles_y;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const size_t lds = (size_t)(p.K + p.cin) * FIH * FROW * sizeof(float);
-    auto kern = final_kernel<KT>;
+    auto kern = final_kernel<KT, RPT>;
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), 64 * 1024)) return e_;
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, p, tiles_x, tiles_y);
     return (int)hipGetLastError();
+}
+template <int KT>
+int launch_final_t(const FinalParams& p, hipStream_t stream) {
+    // two rows per thread where the 18-row tile fits the 64 KB the kernel may ask for (same bits either way)
+    if ((size_t)(p.K + p.cin) * 18 * FROW * sizeof(float) <= 64 * 1024 && KT <= 16) return launch_final_rt<KT, 2>(p, stream);
+    return launch_final_rt<KT, 1>(p, stream);
 }
 
 
