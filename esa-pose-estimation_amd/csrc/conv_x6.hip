@@ -52,6 +52,9 @@ extern "C" int esa_debug_x6_wg(void* dst) { return (int)hipMemcpyFromSymbol(dst,
 #ifndef X6_ABL
 #define X6_ABL 0
 #endif
+#ifndef X6_C1_JOBS
+#define X6_C1_JOBS 0       // merged launch of the register-resident 1x1 kernel for a module's fuse-up 1x1s: measured slower
+#endif
 #ifndef X6_S2_SINGLE
 #define X6_S2_SINGLE 1    // stride-2 kernels (and the fused stem): 4-row tiles in ONE LDS buffer, two barriers per step
 #endif
@@ -1118,8 +1121,7 @@ bool conv1x1_x6_supported(const ConvParams& p) {
     // tile-stream kernel, which also serves their merged launch — a rule on the layer, never on the batch: the two kernels
     // sum in different orders)
     return p.fmt == FMT_F32 && !p.res && !p.out_f32 && p.nheads <= 1 && (p.Cinp % 32) == 0 && (p.Coutp % 16) == 0 && p.H == p.OH &&
-           p.W == p.OW && (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8) && p.Coutp >= 256 &&
-           !getenv("ESAHRNET_X6_NO_C1");
+           p.W == p.OW && (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8) && p.Coutp >= 256;
 }
 int launch_conv1x1_x6(const ConvParams& p, hipStream_t stream) {
     if (!conv1x1_x6_supported(p)) return (int)hipErrorInvalidValue;
@@ -1133,7 +1135,7 @@ int launch_conv1x1_x6(const ConvParams& p, hipStream_t stream) {
     }
 }
 bool conv1x1_x6_jobs_supported(const ConvParams* ps, int n) {
-    if (n < 2 || n > X6_C1_MAXJOBS || !getenv("ESAHRNET_X6_C1_JOBS")) return false;      // (fuse-up 1x1s: 24 -> 30, 32 -> 48 us; opt-in)
+    if (n < 2 || n > X6_C1_MAXJOBS || !X6_C1_JOBS) return false;      // (fuse-up 1x1s: 24 -> 30, 32 -> 48 us: off, a build flag)
     for (int j = 0; j < n; ++j) {
         const int nch = ps[j].Cinp / 32;
         if (!conv1x1_x6_supported(ps[j]) || (nch != 2 && nch != 4 && nch != 8)) return false;
