@@ -135,8 +135,133 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) 
     *reinterpret_cast<uint4*>(o + 16) = lo;
 }
 
+// ---- 2x2 pixel blocks (fp32-grade mode, even H and W, every up-sampled term at ratio >= 2) --------------------------------
+// The kernel above issues 2 + 8 NU 16-byte loads per 32 bytes it writes: with three up-sampled terms the texture path (64
+// B/clk/CU), not HBM, sets its rate (2.8-3.3 TB/s on the full-resolution levels).  Here a thread owns a 2x2 block of
+// pixels x 8 channels: at ratio >= 2 the four pixels' taps lie in a 3x3 neighbourhood of the source — rows {i0(Y), i1(Y),
+// i1(Y+1)}, and i0(Y+1) is one of the first two — and in ONE 2x2 cell for exact ratios 4 and 8, so the block loads 9 (or 4)
+// source pixels per term instead of 16.  Every pixel evaluates exactly the expression of fuse_kernel on exactly its own
+// four taps (picked from the loaded set by v_cndmask): bit-identical results.
+template <int NS, int NU>
+__global__ __launch_bounds__(256) void fuse2x2_kernel(FuseParams p, FuseScales fs, int cell_mask) {
+    const int G = p.Cp >> 3, W2 = p.W >> 1, H2 = p.H >> 1;
+    const unsigned u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= (unsigned)(W2 * G)) return;
+    const int bx = (int)(u / (unsigned)G);
+    const int c8 = (int)(u - (unsigned)bx * (unsigned)G);
+    const int brow = blockIdx.y;                  // n*H2 + by
+    const int n = brow / H2, by = brow - n * H2;
+    const int X = 2 * bx, Y = 2 * by;
+    const int pixb = p.Cp * 4;
+    const size_t row0 = (size_t)n * p.H + Y;      // image row of the block's first pixel row
+
+    float acc[4][8];                              // pixel j = dy*2 + dx
+    if (NS > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            load8<FMT_F32>(p.x[0] + ((row0 + (j >> 1)) * p.W + X + (j & 1)) * (size_t)pixb, c8, acc[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+    }
+#pragma unroll
+    for (int t = 1; t < NS; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[8];
+            load8<FMT_F32>(p.x[t] + ((row0 + (j >> 1)) * p.W + X + (j & 1)) * (size_t)pixb, c8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] += v[i];
+        }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int t = NS + k;
+        const int h = p.h[t], w = p.w[t];
+        const Lerp ly[2] = {lerp_scaled(Y, h, fs.sy[t]), lerp_scaled(Y + 1, h, fs.sy[t])};
+        const Lerp lx[2] = {lerp_scaled(X, w, fs.sx[t]), lerp_scaled(X + 1, w, fs.sx[t])};
+        // loaded rows a = i0(Y), b = i1(Y), c = i1(Y+1); pixel row 1 reads (i0(Y+1) in {a, b}, c); columns likewise
+        const char* base = p.x[t] + (size_t)n * h * w * (size_t)pixb;
+        const char* ra = base + (size_t)ly[0].i0 * w * (size_t)pixb;
+        const char* rb = base + (size_t)ly[0].i1 * w * (size_t)pixb;
+        const char* rc = base + (size_t)ly[1].i1 * w * (size_t)pixb;
+        const int ca = lx[0].i0 * pixb, cb = lx[0].i1 * pixb, cc = lx[1].i1 * pixb;
+        const bool sely = ly[1].i0 != ly[0].i0, selx = lx[1].i0 != lx[0].i0;
+        const bool cell = (cell_mask >> t) & 1;   // exact ratio 4 / 8 in both directions: the block's pixels share one 2x2 cell
+        if (cell) {         // (wave-uniform) one 2x2 cell serves the four pixels: no selection
+            float v00[8], v01[8], v10[8], v11[8];
+            load8<FMT_F32>(ra + ca, c8, v00);
+            load8<FMT_F32>(ra + cb, c8, v01);
+            load8<FMT_F32>(rb + ca, c8, v10);
+            load8<FMT_F32>(rb + cb, c8, v11);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dy = j >> 1, dx = j & 1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    acc[j][i] += ly[dy].l0 * (lx[dx].l0 * v00[i] + lx[dx].l1 * v01[i]) + ly[dy].l1 * (lx[dx].l0 * v10[i] + lx[dx].l1 * v11[i]);
+            }
+        } else {
+            float v[3][3][8];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const char* rr = r == 0 ? ra : r == 1 ? rb : rc;
+                load8<FMT_F32>(rr + ca, c8, v[r][0]);
+                load8<FMT_F32>(rr + cb, c8, v[r][1]);
+                load8<FMT_F32>(rr + cc, c8, v[r][2]);
+            }
+            // first column of the dx = 1 pixels (i0(X+1) is column a or b), per loaded row; then the first row of the
+            // dy = 1 pixels (row a or b) — the second taps are column c / row c
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float c0[3][2], c1[3][2];       // [row][dx]: the pixel column's two taps in loaded row r
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    c0[r][0] = v[r][0][i]; c1[r][0] = v[r][1][i];
+                    c0[r][1] = selx ? v[r][1][i] : v[r][0][i]; c1[r][1] = v[r][2][i];
+                }
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float a0 = lx[dx].l0 * c0[0][dx] + lx[dx].l1 * c1[0][dx];      // row a, interpolated along x
+                    const float b0 = lx[dx].l0 * c0[1][dx] + lx[dx].l1 * c1[1][dx];      // row b
+                    const float g0 = lx[dx].l0 * c0[2][dx] + lx[dx].l1 * c1[2][dx];      // row c
+                    acc[dx][i] += ly[0].l0 * a0 + ly[0].l1 * b0;
+                    acc[2 + dx][i] += ly[1].l0 * (sely ? b0 : a0) + ly[1].l1 * g0;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one term's sources in registers at a time
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (p.relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = relu1(acc[j][i]);
+        }
+        char* o = p.y + ((row0 + (j >> 1)) * p.W + X + (j & 1)) * (size_t)pixb + c8 * 32;
+        *reinterpret_cast<f32x4*>(o) = f32x4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+        *reinterpret_cast<f32x4*>(o + 16) = f32x4{acc[j][4], acc[j][5], acc[j][6], acc[j][7]};
+    }
+}
+
 template <int NS, int NU>
 int launch_fuse_t(const FuseParams& p, const FuseScales& fs, hipStream_t stream) {
+    // fp32-grade mode, even grid, every up-sampled term at half the resolution or less: the 2x2-block kernel
+    bool blocks = p.fmt == FMT_F32 && NU > 0 && !(p.H & 1) && !(p.W & 1);
+    int cell_mask = 0;
+    for (int t = NS; t < NS + NU && blocks; ++t) {
+        if (2 * p.h[t] > p.H || 2 * p.w[t] > p.W) blocks = false;
+        const bool exact = p.h[t] > 0 && p.w[t] > 0 && p.H % p.h[t] == 0 && p.W % p.w[t] == 0;
+        const int ry = exact ? p.H / p.h[t] : 0, rx = exact ? p.W / p.w[t] : 0;
+        if ((ry == 4 || ry == 8) && (rx == 4 || rx == 8)) cell_mask |= 1 << t;
+    }
+    if (blocks) {
+        const long long per_row = (long long)(p.W >> 1) * (p.Cp >> 3), rows = (long long)p.N * (p.H >> 1);
+        if (per_row <= 0 || rows <= 0 || rows > 0x7fffffffLL || per_row > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL((fuse2x2_kernel<NS, NU>), dim3((unsigned)((per_row + 255) / 256), (unsigned)rows), dim3(256), 0, stream, p, fs, cell_mask);
+        return (int)hipGetLastError();
+    }
     const long long per_row = (long long)p.W * (p.Cp >> 3);
     const long long rows = (long long)p.N * p.H;
     if (per_row <= 0 || rows <= 0 || rows > 0x7fffffffLL || per_row > 0x7fffffffLL) return (int)hipErrorInvalidValue;
