@@ -52,6 +52,9 @@ extern "C" int esa_debug_x6_wg(void* dst) { return (int)hipMemcpyFromSymbol(dst,
 #ifndef X6_ABL
 #define X6_ABL 0
 #endif
+#ifndef X6_KG_SKEW
+#define X6_KG_SKEW 1
+#endif
 #ifndef X6_C1_JOBS
 #define X6_C1_JOBS 0       // merged launch of the register-resident 1x1 kernel for a module's fuse-up 1x1s: measured slower
 #endif
@@ -169,7 +172,10 @@ struct X6Cfg {
     static constexpr int ROWS = (NR - 1) * S + KS;          // input rows a wave touches
     // B-operand reads (ds_read_b128: lane groups pair k-groups {0,1} and {2,3}, one term per instruction) want the
     // planes of a k-group pair congruent mod 256 B at stride 1 and one 16-byte slot apart at stride 2 (conv_cfg.h)
-    __host__ __device__ static constexpr int plane_off(int g, int t) { return (g * 3 + t) * PLANE + (S == 2 ? (g & 1) * 16 : 0); }
+    // Staging writes (a ds_write_b128 group = 2 pixels x the 4 k-groups): k-groups {0,1} share their banks by the read rule;
+    // the pair {2,3} sits 64 bytes further so that a pixel's four writes are 2-way, not 4-way, conflicts (X6_KG_SKEW)
+    __host__ __device__ static constexpr int kg_skew(int g) { return (S == 2 ? (g & 1) * 16 : 0) + (X6_KG_SKEW ? (g >> 1) * 64 : 0); }
+    __host__ __device__ static constexpr int plane_off(int g, int t) { return (g * 3 + t) * PLANE + kg_skew(g); }
     static_assert(LDS <= 160 * 1024, "tile buffers exceed the CU's LDS");
 };
 
@@ -248,6 +254,8 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         for (int i = tid; i < 2 * 4 * 10 * 8; i += C::NT) w1s[i] = stem.w1[i];      // (published by the prologue's barrier)
     }
     // ---- staging map: thread -> (k-group sg, tile pixel q0 + QSTEP*it), fixed for the launch ----
+    // (measured: 8 consecutive lanes = 8 pixels of ONE k-group makes the ds_write_b128 groups conflict-free but the global loads of
+    // a lane quad touch four lines: 1 % fewer cycles per step in the trace, nothing in the network)
     const int sg = tid & 3, q0 = tid >> 2;
     int qyx[XITER];                             // tile-local (row << 8 | column), -1 beyond the tile
 #pragma unroll
@@ -314,7 +322,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             xn[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, so + 64, 0);
         }
     };
-    char* const xwr = smem + q0 * 16 + sg * (3 * C::PLANE) + (S == 2 ? (sg & 1) * 16 : 0);      // plane_off(sg, 0) + pixel slot
+    char* const xwr = smem + q0 * 16 + sg * (3 * C::PLANE) + (S == 2 ? (sg & 1) * 16 : 0) + (X6_KG_SKEW ? (sg >> 1) * 64 : 0);      // plane_off(sg, 0) + pixel slot
     // unit `it` of the half in flight: split into three exact bf16 terms, three 16-byte LDS writes
     // split into three exact bf16 terms + three 16-byte LDS writes of one unit's 8 channels
     auto emit_unit = [&](int buf, int it, const u32x4 (&src)[2]) __attribute__((always_inline)) {
@@ -481,8 +489,8 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     asm volatile("" : "+v"(bv));                // (waited for here, once: at the loop head hipcc would otherwise merge "bias pending
                                                 // behind 27 weight loads" into every iteration's state and drain vmcnt(0) there)
 
-    const char* const xrd0 = smem + ((rg * NR * S) * C::IW + px * S) * 16 + C::plane_off(0, 0) + g * (3 * C::PLANE) +
-                             (S == 2 ? (g & 1) * 16 : 0);
+    const char* const xrd0 = smem + ((rg * NR * S) * C::IW + px * S) * 16 + g * (3 * C::PLANE) + (S == 2 ? (g & 1) * 16 : 0) +
+                             (X6_KG_SKEW ? (g >> 1) * 64 : 0);       // plane_off(g, 0) + pixel slot
     f32x4 acc[NR];
     int buf = 0;
     int pstep = 0;
@@ -573,8 +581,17 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             constexpr int RING = PREF ? KS + S : KS;
             constexpr int NSLOT = 6 * KS;                        // MFMAs of a row
             bf16x8 xw[RING][3];
+            bf16x8 dsink[3] = {};         // (X6_ABL & 128 only)
             auto read_rows = [&](int lo, int hi) __attribute__((always_inline)) {
                 if ((X6_ABL & 8) && lo > 0) return;
+                if ((X6_ABL & 128) && lo > 0) {     // (timing experiment: the reads are issued, nothing waits for them)
+#pragma unroll
+                    for (int j = lo; j <= hi; ++j)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            asm volatile("ds_read_b128 %0, %1" : "+v"(dsink[t]) : "v"((uint32_t)(uintptr_t)(xrd - smem) + (uint32_t)((j * C::IW + kx) * 16 + t * C::PLANE)));
+                    return;
+                }
 #pragma unroll
                 for (int j = lo; j <= hi; ++j)
 #pragma unroll
@@ -637,6 +654,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                 }
                 tprev = sm;
             });
+            if (X6_ABL & 128) asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(dsink[0]), "v"(dsink[1]), "v"(dsink[2]));
             __builtin_amdgcn_sched_barrier(0);
         };
         constexpr auto F = std::false_type{};
