@@ -55,6 +55,9 @@ extern "C" int esa_debug_x6_wg(void* dst) { return (int)hipMemcpyFromSymbol(dst,
 #ifndef X6_KG_SKEW
 #define X6_KG_SKEW 1
 #endif
+#ifndef X6_W2BUF
+#define X6_W2BUF 1      // 3x3: two weight thirds in registers (72 VGPRs), the step loop unrolled by two
+#endif
 #ifndef X6_C1_JOBS
 #define X6_C1_JOBS 0       // merged launch of the register-resident 1x1 kernel for a module's fuse-up 1x1s: measured slower
 #endif
@@ -436,16 +439,20 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         }
     };
 
-    // ---- weights: registers wf[m][tap][term]; third kx = taps ky*KS + kx ----
-    bf16x8 wf[TAPS][3];
-    auto load_w = [&](int ct, int ch, int kx) __attribute__((always_inline)) {
+    // ---- weights in registers; third kx = taps ky*KS + kx (KS fragments x 3 terms) ----
+    // W2 (3x3): TWO thirds live — phase i (three per step, counted across steps) multiplies from buffer i & 1 while the third
+    // of phase i + 1 lands in the other one, which phase i - 1 has finished with: 72 weight registers instead of 108.  The
+    // buffer of a phase is a compile-time index, so the step loop is unrolled by two (PAR = step parity).  1x1: wf[1][3].
+    constexpr bool W2 = KS == 3 && X6_W2BUF;
+    bf16x8 wf[W2 ? 2 * KS : TAPS][3];
+    auto load_w = [&](int ct, int ch, int kx, int b) __attribute__((always_inline)) {     // b: buffer (W2 only)
         const uint4* ws = p.w + ((size_t)((ct * CT + cw) * nchunks + ch) * TAPS) * 3 * 64 + lane;
         if (X6_ABL & 4) return;
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
             for (int t = 0; t < 3; ++t)
-                wf[ky * KS + kx][t] = __builtin_bit_cast(bf16x8, ws[((ky * KS + kx) * 3 + t) * 64]);
+                wf[W2 ? b * KS + ky : ky * KS + kx][t] = __builtin_bit_cast(bf16x8, ws[((ky * KS + kx) * 3 + t) * 64]);
     };
     auto load_bias = [&](int ct) { return *reinterpret_cast<const f32x4*>(p.bias + (ct * CT + cw) * 16 + g * 4); };
 
@@ -483,8 +490,12 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
     int sidx = 0;
     if constexpr (DEEP) load_next(nxt);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (W2) {
+        load_w(cur.ct, 0, 0, 0);            // step 0's first third; the others are loaded one phase ahead inside the steps
+    } else {
 #pragma unroll
-    for (int kx = 0; kx < KS; ++kx) load_w(cur.ct, 0, kx);
+        for (int kx = 0; kx < KS; ++kx) load_w(cur.ct, 0, kx, 0);
+    }
     f32x4 bv = load_bias(cur.ct);
     asm volatile("" : "+v"(bv));                // (waited for here, once: at the loop head hipcc would otherwise merge "bias pending
                                                 // behind 27 weight loads" into every iteration's state and drain vmcnt(0) there)
@@ -507,7 +518,9 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
 #else
 #define X6_TR(EV)
 #endif
-    while (true) {
+    auto step = [&](auto par_c) __attribute__((always_inline)) -> bool {      // true: that was this workgroup's last step
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr int B0 = PAR, B1 = PAR ^ 1;       // W2: buffers of phases 0 / 2 and of phase 1
         // Two workgroups share a CU (X6_MODE 2): the hardware arbitrates the matrix pipe by priority, then AGE — left alone
         // the older workgroup runs at full speed, the younger one on the leftovers, and finishes its equal share of the items
         // alone on a half-empty CU.  The priority alternates per step between the grid's halves (workgroups b and b + G/2
@@ -571,8 +584,9 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         // other LDS buffer during the LAST rows of this phase, one unit per row, in the issue shadow of the row's MFMAs
         // (-1: none).  LDS operand reads run one output row ahead of the MFMAs that consume them, pinned by a
         // sched_barrier: left alone, hipcc sinks each ds_read next to its first use and waits for it.
-        auto phase = [&](auto kx_c, auto epi_c, auto wh_c) __attribute__((always_inline)) {
+        auto phase = [&](auto kx_c, auto epi_c, auto wh_c, auto wb_c) __attribute__((always_inline)) {
             constexpr int kx = decltype(kx_c)::value;
+            constexpr int WB = decltype(wb_c)::value;            // W2: weight buffer of this phase
             constexpr bool EPI = decltype(epi_c)::value;         // last phase of the item: rows leave as they complete
             constexpr int WH = decltype(wh_c)::value;
             // LDS operand reads run one output row ahead (RING = the input rows of output rows r and r + 1) — except in the
@@ -622,7 +636,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                         constexpr int ky = i < 5 * KS ? i / 5 : i - 5 * KS, pr = i < 5 * KS ? i % 5 : 5;
                         constexpr int tp = ky * KS + kx, w = (r * S + ky) % RING;
                         constexpr int wa = pr == 0 ? 2 : (pr == 2 || pr == 3) ? 1 : 0, xb = pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
-                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tp][wa], xw[w][xb], sm, 0, 0, 0);
+                        sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[W2 ? WB * KS + ky : tp][wa], xw[w][xb], sm, 0, 0, 0);
                     });
                 }
                 if constexpr (r > 0) {
@@ -662,23 +676,28 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
         constexpr auto W0 = std::integral_constant<int, 0>{};
         constexpr auto W1 = std::integral_constant<int, XH < XITER ? 1 : -1>{};
         constexpr auto WN = std::integral_constant<int, -1>{};
+        constexpr auto IB0 = std::integral_constant<int, B0>{};
+        constexpr auto IB1 = std::integral_constant<int, B1>{};
         if constexpr (KS == 3 && NBUF == 1) {
             // single tile buffer: the whole next tile -> registers now, -> LDS between the two barriers behind the phases
             load_tile(nxt, H0);
+            if constexpr (W2) load_w(cur.ct, cur.c, 1, B1);       // this step's second third (the buffer phase 2 of the step before has left)
             __builtin_amdgcn_sched_barrier(0);
             X6_TR(2)
-            phase(std::integral_constant<int, 0>{}, F, WN);
+            phase(std::integral_constant<int, 0>{}, F, WN, IB0);
             asm volatile("" : "+v"(bvn));
             X6_TR(3)
-            load_w(wct, wch, 0);
+            if constexpr (W2) load_w(cur.ct, cur.c, 2, B0);       // this step's last third
+            else load_w(wct, wch, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            phase(std::integral_constant<int, 1>{}, F, WN);
+            phase(std::integral_constant<int, 1>{}, F, WN, IB1);
             X6_TR(4)
-            load_w(wct, wch, 1);
+            if constexpr (W2) load_w(wct, wch, 0, B1);            // the next step's first third
+            else load_w(wct, wch, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
-            phase(std::integral_constant<int, 2>{}, T, WN);
+            phase(std::integral_constant<int, 2>{}, T, WN, IB0);
             X6_TR(5)
-            load_w(wct, wch, 2);
+            if constexpr (!W2) load_w(wct, wch, 2, 0);
             __syncthreads();            // every wave is done reading the tile
             if constexpr (STEM) stage_stem(0, nxt, (sidx + 1) & 1);
             else write_tile(0, H0);     // (published by the barrier at the top of the next step)
@@ -694,9 +713,10 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             } else {
                 load_tile(nxt, H0);
             }
+            if constexpr (W2) load_w(cur.ct, cur.c, 1, B1);       // this step's second third (the buffer phase 2 of the step before has left)
             __builtin_amdgcn_sched_barrier(0);
             X6_TR(2)
-            phase(std::integral_constant<int, 0>{}, F, W0);
+            phase(std::integral_constant<int, 0>{}, F, W0, IB0);
             asm volatile("" : "+v"(bvn));       // the bias load is complete here (older than the tile half just consumed): waited
                                                 // for now, with a counted vmcnt, not at the next step's start behind the weight loads
             X6_TR(3)
@@ -705,15 +725,17 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (XH < XITER) load_tile(nxt, H1);
-            load_w(wct, wch, 0);
+            if constexpr (W2) load_w(cur.ct, cur.c, 2, B0);       // this step's last third
+            else load_w(wct, wch, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            phase(std::integral_constant<int, 1>{}, F, W1);
+            phase(std::integral_constant<int, 1>{}, F, W1, IB1);
             X6_TR(4)
-            load_w(wct, wch, 1);
+            if constexpr (W2) load_w(wct, wch, 0, B1);            // the next step's first third
+            else load_w(wct, wch, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
-            phase(std::integral_constant<int, 2>{}, T, WN);
+            phase(std::integral_constant<int, 2>{}, T, WN, IB0);
             X6_TR(5)
-            load_w(wct, wch, 2);
+            if constexpr (!W2) load_w(wct, wch, 2, 0);
         } else {
             if constexpr (DEEP) {
 #pragma unroll
@@ -723,9 +745,9 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                 load_tile(nxt, H0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            phase(std::integral_constant<int, 0>{}, T, W0);
+            phase(std::integral_constant<int, 0>{}, T, W0, IB0);
             asm volatile("" : "+v"(bvn));
-            load_w(wct, wch, 0);
+            load_w(wct, wch, 0, 0);
         }
         bv = bvn;
         X6_TR(6)
@@ -737,7 +759,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
 #endif
         if constexpr (STEM) raw_commit(sidx & 1);       // crop of step s+2 (this buffer's readers were step s-1's staging)
         ++sidx;
-        if (!nxt.ok) break;
+        if (!nxt.ok) return true;
         cur = nxt;
         if constexpr (STEM) {
             nxt = nn;
@@ -746,6 +768,15 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             if (nxt.c == 0) tile_offsets(nxt);      // (a uniform branch around integer VALU only)
         }
         if constexpr (NBUF == 2) buf ^= 1;
+        return false;
+    };
+    if constexpr (W2) {
+        while (true) {
+            if (step(std::integral_constant<int, 0>{})) break;
+            if (step(std::integral_constant<int, 1>{})) break;
+        }
+    } else {
+        while (!step(std::integral_constant<int, 0>{})) {}
     }
 }
 
