@@ -58,6 +58,12 @@ extern "C" int esa_debug_x6_wg(void* dst) { return (int)hipMemcpyFromSymbol(dst,
 #ifndef X6_W2BUF
 #define X6_W2BUF 1      // 3x3: two weight thirds in registers (72 VGPRs), the step loop unrolled by two
 #endif
+#ifndef X6_READ_PIN
+#define X6_READ_PIN 1
+#endif
+#ifndef X6_PREF_DIST
+#define X6_PREF_DIST 1      // (2: measured, no change — the reads cost issue cycles, not exposed latency)
+#endif
 #ifndef X6_C1_JOBS
 #define X6_C1_JOBS 0       // merged launch of the register-resident 1x1 kernel for a module's fuse-up 1x1s: measured slower
 #endif
@@ -592,7 +598,8 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             // LDS operand reads run one output row ahead (RING = the input rows of output rows r and r + 1) — except in the
             // single-buffer stride-2 kernels, which are short of registers: there a row's new input rows are read at its start
             constexpr bool PREF = NBUF == 2;
-            constexpr int RING = PREF ? KS + S : KS;
+            constexpr int PD = PREF ? (S == 1 && KS == 3 ? X6_PREF_DIST : 1) : 0;      // output rows the LDS reads run ahead
+            constexpr int RING = KS + PD * S;
             constexpr int NSLOT = 6 * KS;                        // MFMAs of a row
             bf16x8 xw[RING][3];
             bf16x8 dsink[3] = {};         // (X6_ABL & 128 only)
@@ -612,7 +619,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                     for (int t = 0; t < 3; ++t)
                         xw[j % RING][t] = *reinterpret_cast<const bf16x8*>(xrd + (j * C::IW + kx) * 16 + t * C::PLANE);
             };
-            read_rows(0, KS - 1);
+            read_rows(0, KS - 1 + (PD > 1 ? (PD - 1) * S : 0));
             if (EPI) {
 #pragma unroll
                 for (int t = 0; t < RCN - 1 && t < NR; ++t) res_load(t);
@@ -626,7 +633,10 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
                 // (The wave issues in order and hipcc puts everything else behind the row's MFMAs; what fills the matrix pipe
                 // meanwhile is the SIMD's other wave.)
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (PREF && r + 1 < NR) read_rows(r * S + KS, (r + 1) * S + KS - 1);
+                if constexpr (PREF && r + PD < NR) {
+                    read_rows((r + PD - 1) * S + KS, (r + PD) * S + KS - 1);
+                    if (X6_READ_PIN) __builtin_amdgcn_sched_barrier(0);     // (else hipcc places the reads BEHIND this row's MFMAs)
+                }
                 if constexpr (!PREF && r > 0 && r < NR) read_rows((r - 1) * S + KS, r * S + KS - 1);
                 if constexpr (r < NR) {
                     sm = f32x4{0.f, 0.f, 0.f, 0.f};
