@@ -64,6 +64,9 @@ extern "C" int esa_debug_x6_wg(void* dst) { return (int)hipMemcpyFromSymbol(dst,
 #ifndef X6_PREF_DIST
 #define X6_PREF_DIST 1      // (2: measured, no change — the reads cost issue cycles, not exposed latency)
 #endif
+#ifndef X6_S2_PREF
+#define X6_S2_PREF 1
+#endif
 #ifndef X6_C1_JOBS
 #define X6_C1_JOBS 0       // merged launch of the register-resident 1x1 kernel for a module's fuse-up 1x1s: measured slower
 #endif
@@ -597,7 +600,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             constexpr int WH = decltype(wh_c)::value;
             // LDS operand reads run one output row ahead (RING = the input rows of output rows r and r + 1) — except in the
             // single-buffer stride-2 kernels, which are short of registers: there a row's new input rows are read at its start
-            constexpr bool PREF = NBUF == 2;
+            constexpr bool PREF = NBUF == 2 || (X6_S2_PREF && !STEM);      // (the single-buffer kernels: since the two-thirds weight registers)
             constexpr int PD = PREF ? (S == 1 && KS == 3 ? X6_PREF_DIST : 1) : 0;      // output rows the LDS reads run ahead
             constexpr int RING = KS + PD * S;
             constexpr int NSLOT = 6 * KS;                        // MFMAs of a row
