@@ -204,7 +204,7 @@ __device__ __forceinline__ int x6_div(int b, int d, uint32_t m) {
 
 struct X6Pos {            // one (item, chunk) step of the workgroup's stream
     int item, c, n, oy0, ox0, ct;
-    bool ok;
+    int ok;                 // (an int: a trailing bool makes hipcc copy the struct's padding bytes through scratch memory)
 };
 
 // STEM (fused stem, launch_stem_fused_x6): the input tensor of this 3x3 stride-2 convolution — conv1 + bn1 + ReLU of the raw
@@ -600,7 +600,7 @@ __device__ __forceinline__ void x6_body(const ConvParams& p, const X6Geo& geo, c
             constexpr int WH = decltype(wh_c)::value;
             // LDS operand reads run one output row ahead (RING = the input rows of output rows r and r + 1) — except in the
             // single-buffer stride-2 kernels, which are short of registers: there a row's new input rows are read at its start
-            constexpr bool PREF = NBUF == 2 || (X6_S2_PREF && !STEM);      // (the single-buffer kernels: since the two-thirds weight registers)
+            constexpr bool PREF = NBUF == 2 || X6_S2_PREF;      // (the single-buffer kernels: since the two-thirds weight registers)
             constexpr int PD = PREF ? (S == 1 && KS == 3 ? X6_PREF_DIST : 1) : 0;      // output rows the LDS reads run ahead
             constexpr int RING = KS + PD * S;
             constexpr int NSLOT = 6 * KS;                        // MFMAs of a row
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void conv_x6_kernel(ConvPara
 constexpr int X6_S2_NBUF = X6_S2_SINGLE ? 1 : 2;        // stride 2: 4-row tiles in one LDS buffer / 2-row tiles in two
 constexpr int X6_S2_NR4 = X6_S2_SINGLE ? 4 : 2, X6_S2_NR2 = X6_S2_SINGLE ? 2 : 1;
 // the stem keeps 2-row tiles in two buffers: its staging holds 9 raw pixels per unit and the 4-row tile's 5 units spill
-constexpr int X6_STEM_NR = 2, X6_STEM_NBUF = 2;
+constexpr int X6_STEM_NR = 4, X6_STEM_NBUF = 1;
 __global__ __launch_bounds__(NTHREADS, 2) void stem_x6_kernel(ConvParams p, X6Geo geo, X6StemSrc stem) {
     x6_body<3, 2, 4, X6_STEM_NR, 4, true, X6_STEM_NBUF>(p, geo, (int)blockIdx.x, (int)gridDim.x, stem);
 }
