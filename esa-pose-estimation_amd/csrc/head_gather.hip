@@ -56,7 +56,9 @@ constexpr int GT_T = 512;        // threads per workgroup: 16 rows of 32 columns
 
 // (HIP's second launch-bound argument is waves per SIMD.  Asking for 4 — two 8-wave workgroups per CU, 128 VGPRs — makes hipcc
 // spill 85 registers; asked for 2 it allocates 127 for the 6-piece variant on its own, which gives the same occupancy.)
-template <int GT_MAXP>
+// F32OUT: the output tensor is plain f32 NHWC (fp32-grade mode) instead of split-bf16 — a template parameter, not a run-time
+// flag: with both stores in one kernel hipcc allocates 162 VGPRs (three waves per SIMD, 0.9 -> 1.2 ms)
+template <int GT_MAXP, bool F32OUT>
 __global__ __launch_bounds__(GT_T, 2) void head_gather_kernel(GatherParams p, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -187,8 +189,19 @@ __global__ __launch_bounds__(GT_T, 2) void head_gather_kernel(GatherParams p, in
                     acc[4] += sm.l0 * u1.x + sm.l1 * w1.x; acc[5] += sm.l0 * u1.y + sm.l1 * w1.y;
                     acc[6] += sm.l0 * u1.z + sm.l1 * w1.z; acc[7] += sm.l0 * u1.w + sm.l1 * w1.w;
                 }
-            if (Y0 < p.H && X0 < p.W)
-                store8_fmt(p.y + (((size_t)n * p.H + Y0) * p.W + X0) * (size_t)(p.Cp * 4) + (size_t)cg * 32, acc, p.fmt == FMT_F32);
+            if (Y0 < p.H && X0 < p.W) {
+                if constexpr (F32OUT) {
+                    char* o = p.y + (((size_t)n * p.H + Y0) * p.W + X0) * (size_t)(p.Cp * 4) + (size_t)cg * 32;
+                    *reinterpret_cast<f32x4*>(o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                    *reinterpret_cast<f32x4*>(o + 16) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+                } else {
+                    uint4 hi, lo;
+                    split8(acc, hi, lo);        // (the address AFTER the split: computed before it, 129 VGPRs = one wave per SIMD less)
+                    char* o = p.y + (((size_t)n * p.H + Y0) * p.W + X0) * (size_t)(p.Cp * 4) + (size_t)cg * 32;
+                    *reinterpret_cast<uint4*>(o) = hi;
+                    *reinterpret_cast<uint4*>(o + 16) = lo;
+                }
+            }
         }
         __syncthreads();        // bs is rewritten by the next x pass; zs now holds the next group
     }
@@ -234,8 +247,8 @@ bool head_gather_supported(int H, int W, const int* h, const int* w, int Cp) {
     return gather_lds(p) <= 150 * 1024 && (p.R[0] * p.Cc[0] + p.R[1] * p.Cc[1]) * 18 <= 8 * GT_T;
 }
 
-int launch_head_gather(GatherParams p, hipStream_t stream) {
-    if (!head_gather_supported(p.H, p.W, p.h, p.w, p.Cp) || (p.fmt != FMT_SB && p.fmt != FMT_F32)) return (int)hipErrorInvalidValue;
+int launch_head_gather(GatherParams p, hipStream_t stream, int fmt) {
+    if (!head_gather_supported(p.H, p.W, p.h, p.w, p.Cp) || (fmt != FMT_SB && fmt != FMT_F32)) return (int)hipErrorInvalidValue;
     fill_windows(p);
     p.ngroups = p.Cp >> 3;
     p.nreal = (p.C + 7) >> 3;
@@ -245,13 +258,11 @@ int launch_head_gather(GatherParams p, hipStream_t stream) {
     const long long nblk = (long long)tiles_x * tiles_y * p.N;
     if (nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)nblk, (unsigned)((p.ngroups + p.gpw - 1) / p.gpw));
-    if ((p.R[0] * p.Cc[0] + p.R[1] * p.Cc[1]) * 18 <= 6 * GT_T) {
-        if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(head_gather_kernel<6>), lds)) return e_;
-        hipLaunchKernelGGL(head_gather_kernel<6>, grid, dim3(GT_T), lds, stream, p, tiles_x, tiles_y);
-    } else {
-        if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(head_gather_kernel<8>), lds)) return e_;
-        hipLaunchKernelGGL(head_gather_kernel<8>, grid, dim3(GT_T), lds, stream, p, tiles_x, tiles_y);
-    }
+    const bool six = (p.R[0] * p.Cc[0] + p.R[1] * p.Cc[1]) * 18 <= 6 * GT_T, f32 = fmt == FMT_F32;
+    auto kern = six ? (f32 ? head_gather_kernel<6, true> : head_gather_kernel<6, false>)
+                    : (f32 ? head_gather_kernel<8, true> : head_gather_kernel<8, false>);
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
+    hipLaunchKernelGGL(kern, grid, dim3(GT_T), lds, stream, p, tiles_x, tiles_y);
     return (int)hipGetLastError();
 }
 

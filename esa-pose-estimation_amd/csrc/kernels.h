@@ -278,10 +278,9 @@ struct GatherParams {
     int N, H, W, C, Cp;                 // C real output channels, Cp padded (the padding is written as zeros)
     int h[2], w[2], zpix[2];
     int R[2], Cc[2], ngroups, nreal, gpw;      // filled by the launcher
-    int fmt = FMT_SB;   // y: FMT_SB or FMT_F32 (z is plain f32 in both)
 };
 bool head_gather_supported(int H, int W, const int* h, const int* w, int Cp);
-int launch_head_gather(GatherParams p, hipStream_t stream);
+int launch_head_gather(GatherParams p, hipStream_t stream, int fmt = FMT_SB);      // fmt of y: FMT_SB or FMT_F32 (z is plain f32 in both)
 
 // ---- arg-max + log-quadratic refine (keypoints.hip) ----------------------------------------
 // idx_out: optional int32 [planes], the flat index (row * W + column) of the arg-max

@@ -1644,8 +1644,8 @@ static int run_forward(esahrnet_handle h, const void* x_dev, int n, int height, 
                     const Tensor& tz = h->tensors[zt[b]];
                     p.z[b] = T(zt[b]); p.h[b] = sp.lh[tz.level]; p.w[b] = sp.lw[tz.level]; p.zpix[b] = tz.Cp * 4;
                 }
-                p.y = T(o.out); p.N = n; p.H = sp.lh[to.level]; p.W = sp.lw[to.level]; p.C = to.C; p.Cp = to.Cp; p.fmt = h->fmt;
-                rc = esa::launch_head_gather(p, stream);
+                p.y = T(o.out); p.N = n; p.H = sp.lh[to.level]; p.W = sp.lw[to.level]; p.C = to.C; p.Cp = to.Cp;
+                rc = esa::launch_head_gather(p, stream, h->fmt);
                 break;
             }
             case OP_ZERO: {
