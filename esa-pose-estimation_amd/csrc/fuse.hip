@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams p, FuseScales fs) 
 // pixels x 8 channels: at ratio >= 2 the four pixels' taps lie in a 3x3 neighbourhood of the source — rows {i0(Y), i1(Y),
 // i1(Y+1)}, and i0(Y+1) is one of the first two — and in ONE 2x2 cell for exact ratios 4 and 8, so the block loads 9 (or 4)
 // source pixels per term instead of 16.  Every pixel evaluates exactly the expression of fuse_kernel on exactly its own
-// four taps (picked from the loaded set by v_cndmask): bit-identical results.
+// four taps (picked from the loaded set by v_cndmask).
 template <int NS, int NU>
 __global__ __launch_bounds__(256) void fuse2x2_kernel(FuseParams p, FuseScales fs, int cell_mask) {
     const int G = p.Cp >> 3, W2 = p.W >> 1, H2 = p.H >> 1;

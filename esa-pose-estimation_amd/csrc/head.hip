@@ -46,7 +46,7 @@ __device__ __forceinline__ LerpT lerp_ac_scaled(int dst, int in, float scale) { 
 }
 
 // RPT = 2: the two pixels of a thread share 12 of their 18 tile reads per channel and every weight, and their
-// multiply-adds pair up as v_pk_fma_f32 (same order per pixel as RPT = 1: bit-identical) — 102 -> ~60 us at W32 256^2.
+// multiply-adds pair up as v_pk_fma_f32 (same order per pixel as RPT = 1) — 102 -> ~60 us at W32 256^2.
 template <int KT, int RPT>
 __global__ __launch_bounds__(256) void final_kernel(FinalParams p, int tiles_x, int tiles_y) {
     constexpr int FTH = 8 * RPT, FIH = FTH + 2;
@@ -186,7 +186,7 @@ int launch_final_rt(const FinalParams& p, hipStream_t stream) {
 }
 template <int KT>
 int launch_final_t(const FinalParams& p, hipStream_t stream) {
-    // two rows per thread where the 18-row tile fits the 64 KB the kernel may ask for (same bits either way)
+    // two rows per thread where the 18-row tile fits the 64 KB the kernel may ask for (same multiply-add order either way)
     if ((size_t)(p.K + p.cin) * 18 * FROW * sizeof(float) <= 64 * 1024 && KT <= 16) return launch_final_rt<KT, 2>(p, stream);
     return launch_final_rt<KT, 1>(p, stream);
 }
