@@ -1025,25 +1025,33 @@ __device__ __forceinline__ void x6_c1_body(const ConvParams& p, const long long 
     constexpr int WIT = (WFR * 64 + NTHREADS - 1) / NTHREADS;
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
     u32x4 wreg[WIT];
+    // (every load of the loop unconditional — clamped indices — and pinned at the top of the iteration: left alone hipcc sinks
+    // the prefetch to the LDS writes that consume it; the bias of the slice sits in LDS: a global load per cout tile was
+    // waited for at the head of every iteration)
     auto prefetch = [&](int m) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            if (it * NTHREADS + tid < WFR * 64) wreg[it] = wsrc[(size_t)m * WFR * 64 + it * NTHREADS + tid];
+        for (int it = 0; it < WIT; ++it) {
+            const int u = it * NTHREADS + tid < WFR * 64 ? it * NTHREADS + tid : WFR * 64 - 1;
+            wreg[it] = wsrc[(size_t)m * WFR * 64 + u];
+        }
     };
     auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < WIT; ++it)
             if (it * NTHREADS + tid < WFR * 64) *reinterpret_cast<u32x4*>(smem + buf * (WFR * 1024) + (it * NTHREADS + tid) * 16) = wreg[it];
     };
+    float* const bias_s = reinterpret_cast<float*>(smem + 2 * WFR * 1024);
+    for (int i = tid; i < (m1 - m0) * 16; i += NTHREADS) bias_s[i] = p.bias[m0 * 16 + i];
     prefetch(m0);
     commit(0);
     __syncthreads();
     const int rfl = relu_floor(p.relu);
     for (int m = m0; m < m1; ++m) {
         const int buf = (m - m0) & 1;
-        if (m + 1 < m1) prefetch(m + 1);
+        prefetch(m + 1 < m1 ? m + 1 : m);
+        __builtin_amdgcn_sched_barrier(0);
         const char* wb = smem + buf * (WFR * 1024) + lane * 16;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + m * 16 + g * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + (m - m0) * 16 + g * 4);
         f32x4 d[PG];
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg) d[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1074,10 +1082,9 @@ __device__ __forceinline__ void x6_c1_body(const ConvParams& p, const long long 
             for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(relu_opt(d[pg][k] + bv[k], rfl));
             if (valid[pg]) *reinterpret_cast<u32x4*>(p.y + (pixel[pg] * (size_t)p.Coutp + m * 16 + g * 4) * 4) = o;
         }
-        if (m + 1 < m1) {
-            commit(buf ^ 1);
-            __syncthreads();
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        commit(buf ^ 1);
+        __syncthreads();
     }
 }
 
@@ -1125,8 +1132,8 @@ int launch_c1_x6_t(const ConvParams& p, hipStream_t stream) {
     const int slices = want < 1 ? 1 : (int)want;
     const int per = (ntile16 + slices - 1) / slices;
     auto kern = conv1x1_x6_kernel<NCH, PG>;
-    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e_;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)((ntile16 + per - 1) / per)), dim3(NTHREADS), lds, stream, p, ntiles, tiles_per_row, per);
+    if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds + per * 64)) return e_;      // + the slice's bias
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)((ntile16 + per - 1) / per)), dim3(NTHREADS), lds + per * 64, stream, p, ntiles, tiles_per_row, per);
     return (int)hipGetLastError();
 }
 
@@ -1220,7 +1227,9 @@ int launch_conv1x1_x6_jobs(const ConvParams* ps, int n, hipStream_t stream) {
         at += (int)nblk;
     }
     for (int k = n; k <= X6_C1_MAXJOBS; ++k) jobs.start[k] = at;
-    const int lds = 2 * 3 * 8 * 1024;
+    int coutp_max = 0;
+    for (int j = 0; j < n; ++j) coutp_max = ps[j].Coutp > coutp_max ? ps[j].Coutp : coutp_max;
+    const int lds = 2 * 3 * 8 * 1024 + coutp_max * 4;       // weights of the widest member + a member's bias
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(conv1x1_x6_jobs_kernel), lds)) return e_;
     hipLaunchKernelGGL(conv1x1_x6_jobs_kernel, dim3((unsigned)at), dim3(NTHREADS), lds, stream, jobs);
     return (int)hipGetLastError();
