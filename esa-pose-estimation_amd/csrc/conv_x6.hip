@@ -67,6 +67,9 @@ extern "C" int esa_debug_x6_wg(void* dst) { return (int)hipMemcpyFromSymbol(dst,
 #ifndef X6_S2_PREF
 #define X6_S2_PREF 1
 #endif
+#ifndef X6_C1_MINCOUT
+#define X6_C1_MINCOUT 256
+#endif
 #ifndef X6_C1_JOBS
 #define X6_C1_JOBS 0       // merged launch of the register-resident 1x1 kernel for a module's fuse-up 1x1s: measured slower
 #endif
@@ -1190,7 +1193,7 @@ bool conv1x1_x6_supported(const ConvParams& p) {
     // tile-stream kernel, which also serves their merged launch — a rule on the layer, never on the batch: the two kernels
     // sum in different orders)
     return p.fmt == FMT_F32 && !p.res && !p.out_f32 && p.nheads <= 1 && (p.Cinp % 32) == 0 && (p.Coutp % 16) == 0 && p.H == p.OH &&
-           p.W == p.OW && (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8) && p.Coutp >= 256;
+           p.W == p.OW && (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8) && p.Coutp >= X6_C1_MINCOUT;
 }
 int launch_conv1x1_x6(const ConvParams& p, hipStream_t stream) {
     if (!conv1x1_x6_supported(p)) return (int)hipErrorInvalidValue;
