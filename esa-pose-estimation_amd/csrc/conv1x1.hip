@@ -63,10 +63,13 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
     u32x4 wreg[NCH];
+    // (the loads of the loop are unconditional and pinned at the top of an iteration — hipcc otherwise sinks them to the LDS
+    // writes that consume them; the bias sits in LDS: as a global load it was waited for in front of every cout tile's first MFMA)
 #define C1_PREFETCH(CH)                                                                       \
     {                                                                                         \
         _Pragma("unroll") for (int it = 0; it < NCH; ++it)                                    \
             wreg[it] = wsrc[(size_t)(CH) * WFR * 64 + it * 256 + tid];                        \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
     }
 #define C1_COMMIT(BUF)                                                                        \
     {                                                                                         \
@@ -74,6 +77,8 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
             *reinterpret_cast<u32x4*>(smem + (BUF) * (WFR * 1024) + (it * 256 + tid) * 16) = wreg[it]; \
     }
     if (c_begin >= nchunks) return;
+    float* const bias_s = reinterpret_cast<float*>(smem + 2 * WFR * 1024);
+    for (int k = tid; k < (nchunks - c_begin) * 32; k += 256) bias_s[k] = p.bias[c_begin * 32 + k];
     C1_PREFETCH(c_begin)
     C1_COMMIT(0)
     __syncthreads();
@@ -82,13 +87,13 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
     for (int pg = 0; pg < PG; ++pg) orow[pg] = p.y + pixel[pg] * (size_t)(p.Coutp * (BF ? 2 : 4));
     for (int cc = c_begin; cc < nchunks; ++cc) {
         const int buf = (cc - c_begin) & 1;
-        if (cc + 1 < nchunks) C1_PREFETCH(cc + 1)
+        C1_PREFETCH(cc + 1 < nchunks ? cc + 1 : cc)
         const char* wb = smem + buf * (WFR * 1024) + lane * 16;
         uint2 pk[PG][2];                             // BF: the two cout tiles' packed quads, stored together below
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int co = cc * 32 + m * 16 + g * 4;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + (cc - c_begin) * 32 + m * 16 + g * 4);
             f32x4 d[PG];
 #pragma unroll
             for (int pg = 0; pg < PG; ++pg) d[pg] = bv;
@@ -141,10 +146,9 @@ __device__ __forceinline__ void conv1x1_body(const ConvParams& p, const long lon
                 if (valid[pg]) *reinterpret_cast<uint4*>(orow[pg] + cob * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
             }
         }
-        if (cc + 1 < nchunks) {
-            C1_COMMIT(buf ^ 1)
-            __syncthreads();
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        C1_COMMIT(buf ^ 1)
+        __syncthreads();
     }
 #undef C1_PREFETCH
 #undef C1_COMMIT
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_jobs_kernel(C1Jobs jobs) {
 
 template <int NCH, bool BF = false>
 int launch_conv1x1_n(const ConvParams& p, hipStream_t stream) {
-    const int lds = 2 * 4 * NCH * 1024;
+    const int lds = 2 * 4 * NCH * 1024 + p.Coutp * 4;        // two weight buffers + the bias
     const int tiles_per_row = (p.W + 15) / 16;
     const long long ntiles = (long long)p.N * p.H * tiles_per_row;
     // two 16-pixel groups per wave for the big bf16 launches (same MFMAs in the same order on every accumulator: the result
@@ -272,7 +276,9 @@ int launch_conv1x1_jobs(const ConvParams* ps, int n, hipStream_t stream) {
         at += (int)nblk;
     }
     for (int k = n; k <= C1_MAXJOBS; ++k) jobs.start[k] = at;
-    const int lds = 2 * 4 * 8 * 1024;                 // the deepest body's two weight buffers
+    int coutp_max = 0;
+    for (int j = 0; j < n; ++j) coutp_max = ps[j].Coutp > coutp_max ? ps[j].Coutp : coutp_max;
+    const int lds = 2 * 4 * 8 * 1024 + coutp_max * 4;       // the deepest body's two weight buffers + a member's bias
     if (const int e_ = ensure_dyn_lds(reinterpret_cast<const void*>(conv1x1_jobs_kernel), lds)) return e_;
     hipLaunchKernelGGL(conv1x1_jobs_kernel, dim3((unsigned)at), dim3(256), lds, stream, jobs);
     return (int)hipGetLastError();
