@@ -2,7 +2,9 @@
 repo snapshot; nothing is JIT-compiled at run time)."""
 from __future__ import annotations
 
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -10,6 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libesahrnet.so")
+USAGE = os.path.join(HERE, "build", "resource_usage.json")      # per kernel: VGPRs, scratch bytes, spills, waves per SIMD (hipcc's remarks)
 SOURCES = ["conv_mfma.hip", "conv_s2c32.hip", "conv_x6.hip", "conv1x1.hip", "stem.hip", "stem_fused.hip", "bblock32.hip", "cbam.hip", "crops.hip", "fuse.hip", "head.hip", "head_fused.hip", "head_fused2.hip", "head_fused_bf.hip", "head_gather.hip", "head_t.hip", "head_x6.hip", "keypoints.hip", "layout.hip", "plan.hip", "pnp_host.hip"]
 # conv_x6.hip: MFMA results that a VALU instruction reads next (the per-row fresh sums) are allocated in VGPRs — with
 # AGPR destinations hipcc copies them out right behind the chain's last MFMA and pads the hazard with s_nop (csrc/conv_x6.hip)
@@ -38,7 +41,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+             "-Rpass-analysis=kernel-resource-usage"]
     flags += os.environ.get("ESA_HIPCC_FLAGS", "").split()       # tuning experiments only
     procs = []
     for s in SOURCES:
@@ -48,18 +52,41 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    usage = {}
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
-        if verbose and out.strip():
-            print(out, file=sys.stderr)
+        usage.update(_parse_usage(s, out))
+        rest = "\n".join(ln for ln in out.splitlines() if "warning:" in ln or "error:" in ln)
+        if verbose and rest.strip():
+            print(rest, file=sys.stderr)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     os.replace(LIB + ".tmp", LIB)
+    with open(USAGE, "w") as f:
+        json.dump(usage, f, indent=1, sort_keys=True)
     return LIB
+
+
+def _parse_usage(src: str, out: str) -> dict:
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> {"<file>:<mangled kernel>": {...}} (tests/test_host_cpu.py reads
+    it: the hot kernels must not touch scratch memory — a struct copied through it or an array hipcc could not promote cost
+    the fused head 35 % — and must keep the occupancy their design counts on)."""
+    res, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch", "VGPRs Spill": "vgpr_spill",
+            "SGPRs Spill": "sgpr_spill", "Occupancy [waves/SIMD]": "waves_per_simd", "LDS Size [bytes/block]": "lds"}
+    for ln in out.splitlines():
+        m = re.search(r"remark: .*?Function Name: (\S+)", ln)
+        if m:
+            cur = res.setdefault(f"{src}:{m.group(1)}", {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z][A-Za-z /\[\]]+?): (\d+)", ln)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return res
 
 
 if __name__ == "__main__":

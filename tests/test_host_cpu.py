@@ -312,3 +312,31 @@ def test_pnp_batch_bad_argument_sets_error_text():
                                 z.ctypes.data_as(C.c_void_p), 0.8, 24, 1, z.ctypes.data_as(C.c_void_p),
                                 z.ctypes.data_as(C.c_void_p))
     assert rc != 0 and "65 keypoints" in lib.esahrnet_last_error().decode()
+
+
+def test_hot_kernels_keep_their_registers():
+    """Compile-time guard for two regressions found on the GPU this round: (1) a kernel of the fp32-grade path touching scratch
+    memory (a struct copied through it, an array hipcc could not promote, spills) — it cost the fused head 35 % and the
+    convolutions their counted vmcnt waits; (2) head_gather losing a wave per SIMD to two extra VGPRs (0.92 -> 1.2 ms).
+    build.py records hipcc's kernel-resource-usage remarks of every build in build/resource_usage.json."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("esa_build", os.path.join(ROOT, "esa-pose-estimation_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()
+    if not os.path.exists(b.USAGE):
+        b.build(force=True)
+    usage = json.load(open(b.USAGE))
+    assert len(usage) > 100
+    hot = [k for k in usage if k.startswith(("conv_x6.hip:", "fuse.hip:", "keypoints.hip:")) or "head_x6_v2_kernel" in k or
+           "final_kernelILi11E" in k or "head_gather_kernel" in k]
+    assert len(hot) > 30
+    for k in hot:
+        u = usage[k]
+        assert u["scratch"] == 0 and u["vgpr_spill"] == 0 and u["sgpr_spill"] == 0, (k, u)
+    for k, u in usage.items():
+        if "conv_x6_jobs_kernel" in k or "conv_x6_kernelILi3E" in k or "stem_x6_kernel" in k or "head_x6_v2_kernel" in k:
+            assert u["waves_per_simd"] >= 2, (k, u)          # two workgroups of four waves per CU
+        if "head_gather_kernelILi6E" in k:
+            assert u["vgprs"] <= 128 and u["waves_per_simd"] == 4, (k, u)
